@@ -1,0 +1,137 @@
+"""Oracle: the reference's own L1 geometry helpers, restated in numpy scalars.
+TEST INFRASTRUCTURE ONLY.
+
+Follows lmi_utils/gadget_utils/pipeline_utils.py:
+  revert_to_origin   :422-476   (reverse operator list; round half-to-even; clamp >= 0)
+  apply_operations   :479-509   (invert each operator, then revert in reverse)
+  fit_im_to_size     :72-142    (centred pad / crop; pad_L = (W-w)//2)
+  resize_image       :23-68     (target size rule `int(w*H/h)`)
+  revert_mask_to_origin :374-405 (shape bookkeeping only here)
+PINNED: tests/golden/l1_geometry.json holds outputs of those reference functions
+run in the build container (tests/golden/make_golden_l1.py), plus the
+known-answer cases of tests/lmi_utils/gadget_utils/test_pipeline_utils.py:117-186,
+:327-390.
+
+dtype rules reproduced (they change the rounding): the per-operator ratio tensors
+are built with `torch.tensor([...])` and are therefore fp32 even when the points
+are float64; Python lists of floats become fp32 points, integer points become fp32
+at the first division.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+
+
+def _as_points(pts):
+    if isinstance(pts, np.ndarray):
+        return pts.copy()
+    a = np.asarray(pts)
+    if a.dtype == np.float64:  # torch.as_tensor(list of python floats) -> fp32
+        a = a.astype(F32)
+    return a
+
+
+def _div(p, r32):
+    if np.issubdtype(p.dtype, np.integer):
+        p = p.astype(F32)
+    return p / r32.astype(p.dtype)
+
+
+def revert_to_origin(pts, operations):
+    p = _as_points(pts)
+    if p.ndim != 2 or p.shape[1] not in (2, 4):
+        raise Exception(f"pts should be Nx2 or Nx4, got shape: {p.shape}")
+    c = p.shape[1]
+    rep = c // 2
+    for op in reversed(operations):
+        if "resize" in op:
+            tw, th, ow, oh = op["resize"]
+            p = _div(p, np.tile(np.array([tw / ow, th / oh], dtype=F32), rep))
+        elif "pad" in op:
+            left, _, top, _ = op["pad"]
+            p = p - np.tile(np.array([left, top]), rep).astype(p.dtype if not np.issubdtype(p.dtype, np.integer) else np.int64)
+        elif "stretch" in op:
+            p = _div(p, np.tile(np.array(op["stretch"], dtype=F32), rep))
+        elif "flip" in op:
+            lr, ud, im_w, im_h = op["flip"]
+            if lr:
+                p[:, 0::2] = im_w - p[:, 0::2]
+            if ud:
+                p[:, 1::2] = im_h - p[:, 1::2]
+        else:
+            raise Exception(f"unsupported operation: {op}")
+    p = np.maximum(np.rint(p), 0)
+    return p
+
+
+def apply_operations(pts, operations):
+    inv = []
+    for op in operations:
+        if "resize" in op:
+            tw, th, ow, oh = op["resize"]
+            inv.append({"resize": [ow, oh, tw, th]})
+        elif "pad" in op:
+            left, right, top, bottom = op["pad"]
+            inv.append({"pad": [-left, -right, -top, -bottom]})
+        elif "stretch" in op:
+            sx, sy = op["stretch"]
+            inv.append({"stretch": [1 / sx, 1 / sy]})
+        elif "flip" in op:
+            inv.append({"flip": list(op["flip"])})
+        else:
+            raise Exception(f"unsupported operation: {op}")
+    return revert_to_origin(pts, inv[::-1])
+
+
+def fit_pads(h: int, w: int, W=None, H=None):
+    """(pad_L, pad_R, pad_T, pad_B) of fit_im_to_size; negative = centred crop."""
+    if W is None and H is None:
+        return 0, 0, 0, 0
+    W = w if W is None else W
+    H = h if H is None else H
+    if W >= w:
+        pl = (W - w) // 2
+        pr = W - w - pl
+    else:
+        pl = (w - W) // 2
+        pr = w - W - pl
+        pl, pr = -pl, -pr
+    if H >= h:
+        pt = (H - h) // 2
+        pb = H - h - pt
+    else:
+        pt = (h - H) // 2
+        pb = h - H - pt
+        pt, pb = -pt, -pb
+    return pl, pr, pt, pb
+
+
+def fit_im_to_size(im: np.ndarray, W=None, H=None, value=0):
+    h, w = im.shape[:2]
+    pl, pr, pt, pb = fit_pads(h, w, W, H)
+    out = im
+    if pl >= 0 and (pl or pr):
+        widths = [(0, 0), (pl, pr)] + [(0, 0)] * (im.ndim - 2)
+        out = np.pad(out, widths, constant_values=value)
+    elif pl < 0 or pr < 0:
+        out = out[:, -pl : out.shape[1] + pr]
+    if pt >= 0 and (pt or pb):
+        widths = [(pt, pb), (0, 0)] + [(0, 0)] * (im.ndim - 2)
+        out = np.pad(out, widths, constant_values=value)
+    elif pt < 0 or pb < 0:
+        out = out[-pt : out.shape[0] + pb]
+    return out, pl, pr, pt, pb
+
+
+def resize_target(h: int, w: int, W=None, H=None):
+    """resize_image's size rule: the missing side is `int(w*H/h)` (truncation)."""
+    if W is None and H is None:
+        return w, h
+    if W is None:
+        W = int(w * H / h)
+    elif H is None:
+        H = int(h * W / w)
+    return W, H
