@@ -1,0 +1,189 @@
+/*
+ * lmi_hip.h -- C ABI of liblmi_hip.so: the MI355X (gfx950) kernels for the YOLOv8
+ * pre/post-processing path that LMI's `Yolov8` wrapper runs around the network.
+ *
+ * The reference exposes a Python class API only (object_detectors/od_base.py:6-37,
+ * object_detectors/yolov8_lmi/model.py:42-324); it has no FFI.  Each entry point
+ * below replaces the Python/torch/cv2/ultralytics call sequence cited in its comment
+ * (paths relative to the reference repository root).  INTEGRATION.md shows the
+ * ctypes stubs a maintainer would add to the reference wrapper.
+ *
+ * Conventions
+ *  - Every pointer marked [device] is a device pointer (e.g. torch `tensor.data_ptr()`),
+ *    every buffer is caller-allocated; the library allocates nothing and keeps no
+ *    per-call global state, so calls on different streams / processes are independent.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls only
+ *    enqueue work; nothing synchronises the host.
+ *  - Return value: 0 = LMI_OK, negative = error (see lmi_status_string); a message for
+ *    the last error on the calling thread is available from lmi_last_error().
+ *  - Arithmetic is compiled with -ffp-contract=off and IEEE-correct fp32 division so
+ *    results are bit-reproducible against the CPU oracle (`oracle/`).
+ */
+#ifndef LMI_HIP_H
+#define LMI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMI_VERSION 100 /* 0.1.0 */
+
+enum lmi_status {
+  LMI_OK = 0,
+  LMI_ERR_BAD_ARG = -1,     /* null pointer, non-positive size, unsupported combination */
+  LMI_ERR_ALIGNMENT = -2,   /* pointer / stride alignment requirement not met */
+  LMI_ERR_WORKSPACE = -3,   /* workspace too small (see *_workspace_bytes) */
+  LMI_ERR_LIMIT = -4,       /* size beyond a compiled-in limit (e.g. max_det > LMI_MAX_DET_CAP) */
+  LMI_ERR_LAUNCH = -5,      /* HIP launch / runtime error (message in lmi_last_error) */
+  LMI_ERR_NO_DEVICE = -6
+};
+
+enum lmi_dtype { LMI_F32 = 0, LMI_F16 = 1, LMI_U8 = 2 };
+
+/* resampler of the letterbox entry: the fixed-point cv2.INTER_LINEAR (default) */
+enum lmi_resize_mode { LMI_RESIZE_CV2_LINEAR = 0 };
+
+#define LMI_MAX_DET_CAP 1024   /* largest max_det lmi_nms_v8 accepts */
+#define LMI_MAX_MASK_DIM 32    /* number of prototype channels (nm) the mask kernels are built for */
+
+int lmi_version(void);
+const char *lmi_status_string(int status);
+const char *lmi_last_error(void);
+/* number of visible HIP devices, or a negative lmi_status */
+int lmi_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Preprocess -- replaces `Yolov8.preprocess` (object_detectors/yolov8_lmi/model.py:112-134):
+ * one uint8 image (H,W,C) with C in {1,3} (a 2-D image is C=1), HWC -> (1,3,H,W), cast,
+ * `/255` by IEEE division (fp16: the fp32 quotient rounded to fp16, as torch-CPU computes it).
+ * No resize, pad or channel swap.
+ *   src  [device] uint8, row_stride bytes between rows (>= W*C)
+ *   dst  [device] (3,H,W) of dst_dtype (LMI_F32 | LMI_F16), contiguous
+ */
+int lmi_preprocess_u8(const void *src, int h, int w, int c, int64_t row_stride,
+                      void *dst, int dst_dtype, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Letterbox geometry (host only, no GPU): aspect-preserving target size and centred pad split
+ * used by lmi_letterbox_u8*.  r = min(dst_h/h, dst_w/w); new = (round(w r), round(h r));
+ * pads follow ultralytics LetterBox `round(d/2 -+ 0.1)`, which equals the reference helpers'
+ * `pad_L = (W-w)//2` (lmi_utils/gadget_utils/pipeline_utils.py:110-131, :152-172) and is the
+ * convention `ops.scale_boxes` (model.py:222) inverts.  stretch != 0 gives the callers'
+ * `cv2.resize(im,(w,h))` stretch (object_detectors/yolov8_lmi/run_model.py:83-87): no pad.
+ *   out6 = {new_w, new_h, pad_left, pad_right, pad_top, pad_bottom}
+ */
+int lmi_letterbox_geometry(int h, int w, int dst_h, int dst_w, int stretch, int32_t out6[6]);
+
+/* one source frame of a ragged batch; the array lives in device memory */
+typedef struct lmi_frame {
+  uint64_t src;        /* [device] uint8 HWC, 3 channels, 16-byte aligned */
+  int32_t h, w;        /* source size */
+  int32_t row_stride;  /* bytes between source rows, >= 3*w */
+  int32_t new_w, new_h;/* resized content size (lmi_letterbox_geometry) */
+  int32_t pad_l, pad_t;/* where the content starts in the destination */
+  int32_t reserved;
+} lmi_frame;
+
+/* Fused letterbox -- replaces the callers' chain around preprocess:
+ *   cv2 BGR->RGB            object_detectors/yolov8_lmi/run_model.py:79, model.py:151-152
+ *   cv2.resize INTER_LINEAR object_detectors/yolov8_lmi/run_model.py:83-87,
+ *                           tests/object_detectors/yolov8_lmi/test_yolov8_model.py:84
+ *   centred constant pad    lmi_utils/gadget_utils/pipeline_utils.py:145-173 (fit_array_to_size)
+ *   HWC->NCHW, cast, /255   object_detectors/yolov8_lmi/model.py:128-133
+ * for a batch of uint8 HWC 3-channel frames -> dst (B,3,dst_h,dst_w) fp32|fp16.  The resampler
+ * reproduces OpenCV's 8-bit INTER_LINEAR fixed-point arithmetic bit for bit (11-bit
+ * coefficients, see oracle/cv2_resize.py).
+ *   frames_host [host]   lmi_frame[batch]: validated (alignment, strides, geometry) and used to
+ *                        size the launch; never dereferenced on the device
+ *   frames_dev  [device] the same array in device memory, read by the kernel
+ *   swap_rb != 0 reverses the channel order (BGR<->RGB); pad_value in 0..255.
+ */
+int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, int batch,
+                     void *dst, int dst_h, int dst_w, int dst_dtype, int pad_value, int swap_rb,
+                     int mode, void *stream);
+
+/* Same, for a batch of equally sized frames stored with a constant image stride: no
+ * descriptor array, geometry is derived from (h,w,dst_h,dst_w,stretch) on the host. */
+int lmi_letterbox_u8_uniform(const void *src, int batch, int h, int w, int64_t row_stride,
+                             int64_t image_stride, void *dst, int dst_h, int dst_w,
+                             int dst_dtype, int pad_value, int swap_rb, int stretch, int mode,
+                             void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * NMS -- replaces `ops.non_max_suppression(preds, conf2, iou, agnostic=, max_det=, nc=)`
+ * (object_detectors/yolov8_lmi/model.py:212; in-tree YOLOv5 analogue
+ * object_detectors/yolov5_lmi/trt/yolov5_trt.py:172-282) including the torchvision greedy NMS
+ * it calls (:267).  Semantics: SURVEY.md 8(a) row a4 / oracle/nms.py.
+ *   pred        [device] fp32 (batch, 4+nc+nm, anchors), contiguous (the head output)
+ *   conf_thres  compared in fp32, strictly (`>`)
+ *   iou_thres   compared as torchvision does: fp32 IoU promoted to double, strictly
+ *   max_wh      class offset (7680 upstream); ignored when agnostic != 0
+ *   max_nms     candidates kept for NMS by score (30000 upstream)
+ *   out_det     [device] fp32 (batch, max_det, 6+nm): x1,y1,x2,y2,conf,cls,coef..., score order;
+ *               rows >= out_count[b] are left untouched
+ *   out_count   [device] int32 (batch)
+ *   out_anchor  [device] int32 (batch, max_det): anchor index of every kept row (parity checks)
+ *   workspace   [device] >= lmi_nms_workspace_bytes(batch, anchors) bytes, 256-byte aligned
+ */
+int64_t lmi_nms_workspace_bytes(int batch, int anchors);
+int lmi_nms_v8(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres,
+               double iou_thres, int agnostic, int max_det, int max_nms, float max_wh,
+               float *out_det, int32_t *out_count, int32_t *out_anchor, void *workspace,
+               int64_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Finalize -- replaces, per image, `ops.scale_boxes(img.shape[2:], pred[:, :4], orig_img.shape)`
+ * + clip (object_detectors/yolov8_lmi/model.py:222; in-tree form yolov5_trt.py:316-341) IN
+ * PLACE on det[..., :4], and the per-class confidence filter `M = confs > thres`
+ * (model.py:223-232, comparison in float64, strict).  It also ranks the survivors so the mask
+ * kernels can write them densely.
+ *   det          [device] fp32 (batch, max_det, det_stride) from lmi_nms_v8 (det_stride = 6+nm)
+ *   count        [device] int32 (batch)
+ *   model_h/w    network input size (img.shape[2:])
+ *   orig_hw      [device] int32 (batch,2) = (H0,W0) per image, or NULL -> every image is
+ *                (uniform_h0, uniform_w0)
+ *   pad_round    1 = ultralytics 8.3.x `round(pad - 0.1)`; 0 = un-rounded pad (YOLOv5 in-tree form)
+ *   thres        [device] double (nc) per-class thresholds, or NULL -> uniform_thres for all
+ *   keep         [device] uint8 (batch, max_det): 1 where M is true
+ *   keep_count   [device] int32 (batch): m_b = number of survivors
+ *   mask_slot    [device] int32 (batch, max_det): dense global rank of each survivor
+ *                (image-major, score order), -1 for dropped rows; may be NULL
+ *   slot_map     [device] int32 (batch*max_det): slot -> b*max_det + i ; may be NULL
+ *   slot_base    [device] int32 (batch+1): first slot of every image, [batch] = number of
+ *                survivors in the whole batch; may be NULL
+ */
+int lmi_finalize_detections(float *det, const int32_t *count, int batch, int max_det,
+                            int det_stride, int nc, int model_h, int model_w,
+                            const int32_t *orig_hw, int uniform_h0, int uniform_w0,
+                            int pad_round, const double *thres, double uniform_thres,
+                            uint8_t *keep, int32_t *keep_count, int32_t *mask_slot,
+                            int32_t *slot_map, int32_t *slot_base, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Masks -- replaces `ops.process_mask_native(proto[i], pred[:, 6:], pred[:, :4],
+ * orig_img.shape[:2])` + `masks[M]` (object_detectors/yolov8_lmi/model.py:235-236; in-tree
+ * YOLOv5 analogue yolov5_trt.py:373-415): logits = coef @ proto on fp32 MFMA, then fused
+ * letterbox-pad crop -> bilinear upsample (align_corners=False) to the ORIGINAL frame -> crop to
+ * the rescaled box -> `> 0`, written once as uint8 (or fp32 0./1.).
+ *   proto      [device] fp32 (batch, 32, mh, mw)
+ *   det, slot_map, slot_base: as produced by lmi_finalize_detections (boxes already rescaled)
+ *   out_masks  [device] survivors' masks written back to back in slot order; with uniform
+ *              originals this is an array (capacity_masks, H0, W0) of out_dtype (LMI_U8|LMI_F32)
+ *   capacity_masks  number of mask planes out_masks can hold; slots beyond it are skipped and
+ *              counted in overflow[0] ([device] int32, may be NULL)
+ *   workspace  [device] >= lmi_mask_workspace_bytes(capacity_masks, mh, mw), 256-byte aligned
+ * Only uniform originals (every image H0 x W0) are supported by this entry.
+ */
+int64_t lmi_mask_workspace_bytes(int64_t capacity_masks, int mh, int mw);
+int lmi_process_mask(const float *proto, int batch, int nm, int mh, int mw, const float *det,
+                     int max_det, int det_stride, const int32_t *slot_map,
+                     const int32_t *slot_base, int h0, int w0, void *out_masks, int out_dtype,
+                     int64_t capacity_masks, int32_t *overflow, void *workspace,
+                     int64_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMI_HIP_H */

@@ -1,0 +1,78 @@
+"""ctypes loader for liblmi_hip.so (the C ABI of include/lmi_hip.h).  No fallback: a missing or
+stale library raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblmi_hip.so")
+
+LMI_F32, LMI_F16, LMI_U8 = 0, 1, 2
+LMI_MAX_DET_CAP = 1024
+
+
+class LmiError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"liblmi_hip: {message} (status {status})")
+        self.status = status
+
+
+class lmi_frame(C.Structure):
+    _fields_ = [("src", C.c_uint64), ("h", C.c_int32), ("w", C.c_int32), ("row_stride", C.c_int32),
+                ("new_w", C.c_int32), ("new_h", C.c_int32), ("pad_l", C.c_int32), ("pad_t", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+# name -> (restype, argtypes); must list every symbol include/lmi_hip.h declares
+SIGNATURES = {
+    "lmi_version": (C.c_int, []),
+    "lmi_status_string": (C.c_char_p, [C.c_int]),
+    "lmi_last_error": (C.c_char_p, []),
+    "lmi_device_count": (C.c_int, []),
+    "lmi_preprocess_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
+    "lmi_letterbox_geometry": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
+    "lmi_letterbox_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_void_p]),
+    "lmi_letterbox_u8_uniform": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "lmi_nms_workspace_bytes": (C.c_int64, [C.c_int, C.c_int]),
+    "lmi_nms_v8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double, C.c_int, C.c_int,
+                             C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "lmi_finalize_detections": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lmi_mask_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
+    "lmi_process_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p,
+                                   C.c_void_p, C.c_int64, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the library.  Raises if it is missing: build it with
+    `python -c "import __graft_entry__ as g; g.build()"` or `make -C object_detectors_amd/csrc`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: the HIP extension is not built (make -C object_detectors_amd/csrc); "
+                          "there is no CPU fallback for this path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        lib = load()
+        msg = lib.lmi_last_error().decode() or lib.lmi_status_string(status).decode()
+        if status == -1:
+            raise ValueError(f"liblmi_hip: {msg}")
+        raise LmiError(status, msg)

@@ -1,0 +1,426 @@
+// Fused letterbox for gfx950: uint8 HWC frames -> cv2.INTER_LINEAR fixed-point resize ->
+// centred constant pad -> optional BGR<->RGB -> /255 -> NCHW fp32|fp16, one pass over HBM.
+// Also the plain `Yolov8.preprocess` transpose/normalise kernel.
+//
+// Replaces (reference paths): object_detectors/yolov8_lmi/run_model.py:79-87 (cv2 resize chain),
+// lmi_utils/gadget_utils/pipeline_utils.py:145-173 (centred pad) and
+// object_detectors/yolov8_lmi/model.py:112-134 (HWC->NCHW, cast, /255).
+//
+// Layout / roofline: HBM-bound.  Per output tile (TW x 8 pixels) a workgroup stages the two
+// source rows of every output row into LDS with 16-byte aligned, bounds-checked buffer loads
+// (coalesced 128-bit), then every lane produces 4 horizontally adjacent pixels x 3 channels and
+// writes one 128-bit store per channel plane.  Algorithmic bytes per image: unique source taps +
+// 3*dst_h*dst_w*sizeof(out)  (SURVEY.md 8(d)).
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 8;  // output rows per tile
+
+struct LbParams {
+  const lmi_frame *frames;  // [device] ragged batch, or nullptr for the uniform form below
+  const uint8_t *src;
+  int h, w;
+  long long row_stride, image_stride;
+  int new_w, new_h, pad_l, pad_t;
+  void *dst;
+  int dst_h, dst_w;
+  int pad_value;
+  int swap_rb;
+  int tiles_x, tiles_y;
+  int pitch;  // LDS bytes per staged source row (multiple of 16)
+};
+
+// One axis of OpenCV's INTER_LINEAR table (resize.cpp, cv::hal::resize): see oracle/cv2_resize.py.
+// fp64 scale and source coordinate, fp32 fraction, int16 weights rounded half-to-even.
+__device__ __forceinline__ void cv_linear_coef(int src_n, int dst_n, int d, bool is_x, int &s, int &w0, int &w1) {
+  double inv_scale = (double)dst_n / (double)src_n;
+  double scale = 1.0 / inv_scale;
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int si = (int)floorf(f);
+  f = f - (float)si;
+  if (is_x) {
+    if (si < 0) { f = 0.f; si = 0; }
+    if (si >= src_n - 1) { f = 0.f; si = src_n - 1; }
+  }
+  w0 = (int)rintf((1.0f - f) * 2048.0f);
+  w1 = (int)rintf(f * 2048.0f);
+  s = si;
+}
+
+// Register-level view of one output element: fp32 as float, fp16 as its bit pattern in a
+// 32-bit register (keeps the per-lane tile in VGPRs instead of a scratch array of __half).
+template <typename OutT>
+struct OutTraits;
+template <>
+struct OutTraits<float> {
+  using reg = float;
+  static __device__ __forceinline__ reg make(int v) { return (float)v / 255.0f; }
+  static __device__ __forceinline__ void store1(float *p, reg v) { *p = v; }
+  static __device__ __forceinline__ void store4(float *p, const reg v[4], bool vec) {
+    if (vec) {
+      *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      p[0] = v[0]; p[1] = v[1]; p[2] = v[2]; p[3] = v[3];
+    }
+  }
+};
+template <>
+struct OutTraits<__half> {
+  using reg = uint32_t;
+  // torch-CPU semantics: the fp32 quotient rounded to fp16
+  static __device__ __forceinline__ reg make(int v) { return (uint32_t)__half_as_ushort(__float2half_rn((float)v / 255.0f)); }
+  static __device__ __forceinline__ void store1(__half *p, reg v) { *reinterpret_cast<uint16_t *>(p) = (uint16_t)v; }
+  static __device__ __forceinline__ void store4(__half *p, const reg v[4], bool vec) {
+    if (vec) {
+      *reinterpret_cast<uint2 *>(p) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+    } else {
+      uint16_t *q = reinterpret_cast<uint16_t *>(p);
+      q[0] = (uint16_t)v[0]; q[1] = (uint16_t)v[1]; q[2] = (uint16_t)v[2]; q[3] = (uint16_t)v[3];
+    }
+  }
+};
+
+// Workgroup = (TW/4) x TH lanes; lane (g, r) produces output pixels x = tile_x0 + 4g .. +3 of
+// row tile_y0 + r.
+template <typename OutT, int TW>
+__global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
+  constexpr int NT = (TW / 4) * TH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // LDS carve (all in the one dynamic array): lut | xs | xa | ytab | rows
+  using TR = OutTraits<OutT>;
+  using reg_t = typename TR::reg;
+  reg_t *lut = reinterpret_cast<reg_t *>(smem);                // 256 entries (1 KiB)
+  int *xs = reinterpret_cast<int *>(smem + 1024);              // TW source pixel index (or -1 = pad column)
+  uint32_t *xa = reinterpret_cast<uint32_t *>(smem + 1024 + 4 * TW);  // TW packed weights a0 | a1<<16
+  int *yrow = reinterpret_cast<int *>(smem + 1024 + 8 * TW);   // 2*TH source row per slot (or -1)
+  int *yshift = yrow + 2 * TH;                                 // 2*TH byte shift of the slot's data in its LDS row
+  uint32_t *yb = reinterpret_cast<uint32_t *>(yshift + 2 * TH);  // TH packed weights b0 | b1<<16
+  unsigned char *rows = smem + ((1024 + 8 * TW + 20 * TH + 15) & ~15);
+
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int tx = blockIdx.x % P.tiles_x;
+  const int ty = blockIdx.x / P.tiles_x;
+  const int x_t0 = tx * TW, y_t0 = ty * TH;
+
+  // frame description (wave-uniform)
+  const uint8_t *src;
+  int h, w, new_w, new_h, pad_l, pad_t;
+  long long stride;
+  if (P.frames != nullptr) {
+    const lmi_frame f = P.frames[b];
+    src = reinterpret_cast<const uint8_t *>(f.src);
+    h = f.h; w = f.w; stride = f.row_stride;
+    new_w = f.new_w; new_h = f.new_h; pad_l = f.pad_l; pad_t = f.pad_t;
+  } else {
+    src = P.src + (long long)b * P.image_stride;
+    h = P.h; w = P.w; stride = P.row_stride;
+    new_w = P.new_w; new_h = P.new_h; pad_l = P.pad_l; pad_t = P.pad_t;
+  }
+
+  OutT *dst = reinterpret_cast<OutT *>(P.dst) + (long long)b * 3 * P.dst_h * P.dst_w;
+  const long long plane = (long long)P.dst_h * P.dst_w;
+  const bool vec = ((P.dst_w & 3) == 0);
+
+  const int g = tid % (TW / 4), r = tid / (TW / 4);
+  const int x0 = x_t0 + 4 * g, y = y_t0 + r;
+
+  // content rectangle clipped to this tile
+  const int cx0 = max(x_t0, pad_l), cx1 = min(min(x_t0 + TW, P.dst_w), pad_l + new_w);
+  const int cy0 = max(y_t0, pad_t), cy1 = min(min(y_t0 + TH, P.dst_h), pad_t + new_h);
+
+  if (cx0 >= cx1 || cy0 >= cy1) {  // tile lies entirely in the border
+    if (y < P.dst_h && x0 < P.dst_w) {
+      const reg_t pv = TR::make(P.pad_value);
+      const reg_t v[4] = {pv, pv, pv, pv};
+      for (int c = 0; c < 3; ++c) {
+        OutT *p = dst + c * plane + (long long)y * P.dst_w + x0;
+        if (x0 + 3 < P.dst_w) TR::store4(p, v, vec);
+        else for (int k = 0; x0 + k < P.dst_w; ++k) TR::store1(p + k, pv);
+      }
+    }
+    return;
+  }
+
+  // ---- tables ------------------------------------------------------------------------------
+  for (int i = tid; i < 256; i += NT) lut[i] = TR::make(i);
+  for (int i = tid; i < TW; i += NT) {
+    int dx = x_t0 + i - pad_l;
+    int s = -1, a0 = 0, a1 = 0;
+    if (dx >= 0 && dx < new_w && x_t0 + i < P.dst_w) cv_linear_coef(w, new_w, dx, true, s, a0, a1);
+    xs[i] = s;
+    xa[i] = (uint32_t)a0 | ((uint32_t)a1 << 16);
+  }
+  for (int i = tid; i < TH; i += NT) {
+    int dy = y_t0 + i - pad_t;
+    int r0 = -1, r1 = -1, b0 = 0, b1 = 0;
+    if (dy >= 0 && dy < new_h && y_t0 + i < P.dst_h) {
+      int s;
+      cv_linear_coef(h, new_h, dy, false, s, b0, b1);
+      r0 = min(max(s, 0), h - 1);
+      r1 = min(max(s + 1, 0), h - 1);
+    }
+    yrow[2 * i] = r0;
+    yrow[2 * i + 1] = r1;
+    yb[i] = (uint32_t)b0 | ((uint32_t)b1 << 16);
+  }
+  __syncthreads();
+
+  // ---- stage source rows ----------------------------------------------------------------------
+  const int sx_min = xs[cx0 - x_t0];
+  const int sx_max = min(xs[cx1 - 1 - x_t0] + 1, w - 1);
+  const int span_b0 = sx_min * 3;                              // first needed byte within a row
+  const int span_bytes = (sx_max - sx_min + 1) * 3;
+  const int nchunk = (span_bytes + 15 + 15) >> 4;              // covers any 0..15 byte alignment shift
+  {
+    const uint32_t frame_bytes = (uint32_t)((long long)(h - 1) * stride + 3LL * w);
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(reinterpret_cast<uintptr_t>(src) & 0xffffffffu));
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(reinterpret_cast<uintptr_t>(src) >> 32));
+    const void *ubase = reinterpret_cast<const void *>(((uintptr_t)hi << 32) | lo);
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ubase), 0,
+                                                  __builtin_amdgcn_readfirstlane(frame_bytes), 0x00020000);
+    const int total = 2 * TH * nchunk;
+    for (int idx = tid; idx < total; idx += NT) {
+      const int slot = idx / nchunk, ch = idx - slot * nchunk;
+      const int row = yrow[slot];
+      if (row < 0) continue;
+      const uint32_t goff = (uint32_t)((long long)row * stride + span_b0);
+      const uint32_t aligned = goff & ~15u;
+      if (ch == 0) yshift[slot] = (int)(goff - aligned);
+      auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, aligned + 16u * ch, 0, 0);
+      *reinterpret_cast<decltype(v) *>(rows + slot * P.pitch + 16 * ch) = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- resample ---------------------------------------------------------------------------------
+  if (y >= P.dst_h || x0 >= P.dst_w) return;
+  reg_t out[3][4];
+  const reg_t pv = lut[P.pad_value];
+  const int r0 = yrow[2 * r];
+  if (r0 < 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out[c][k] = pv;
+  } else {
+    const uint32_t bw = yb[r];
+    const int b0 = (int)(bw & 0xffffu), b1 = (int)(bw >> 16);
+    const unsigned char *row0 = rows + (2 * r) * P.pitch + yshift[2 * r];
+    const unsigned char *row1 = rows + (2 * r + 1) * P.pitch + yshift[2 * r + 1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int s = xs[4 * g + k];
+      if (s < 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[c][k] = pv;
+        continue;
+      }
+      const uint32_t aw = xa[4 * g + k];
+      const int a0 = (int)(aw & 0xffffu), a1 = (int)(aw >> 16);
+      const int off = (s - sx_min) * 3;
+      uint32_t px[2][2];  // [row][0: bytes p..p+3, 1: bytes p+4..p+7]
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const unsigned char *p = (rr == 0 ? row0 : row1) + off;
+        const uintptr_t pa = reinterpret_cast<uintptr_t>(p);
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(pa & ~(uintptr_t)3);
+        const uint32_t sh = (uint32_t)(pa & 3);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        px[rr][0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+        px[rr][1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        // pixel s: byte c ; pixel s+1: byte 3+c
+        const int s00 = (int)((px[0][0] >> (8 * c)) & 0xffu);
+        const int s10 = (int)((px[1][0] >> (8 * c)) & 0xffu);
+        const int s01 = (c == 0) ? (int)(px[0][0] >> 24) : (int)((px[0][1] >> (8 * (c - 1))) & 0xffu);
+        const int s11 = (c == 0) ? (int)(px[1][0] >> 24) : (int)((px[1][1] >> (8 * (c - 1))) & 0xffu);
+        const int h0 = s00 * a0 + s01 * a1;
+        const int h1 = s10 * a0 + s11 * a1;
+        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        out[c][k] = lut[v];
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    OutT *p = dst + (P.swap_rb ? 2 - c : c) * plane + (long long)y * P.dst_w + x0;
+    if (x0 + 3 < P.dst_w) {
+      TR::store4(p, out[c], vec);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (x0 + k < P.dst_w) TR::store1(p + k, out[c][k]);
+    }
+  }
+}
+
+// `Yolov8.preprocess`: HWC uint8 (C = 1 or 3) -> CHW /255.  One lane = 4 pixels of one row.
+template <typename OutT>
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restrict__ src, int h, int w, int c,
+                                                        long long row_stride, OutT *__restrict__ dst) {
+  const int groups = (w + 3) >> 2;
+  const long long total = (long long)h * groups;
+  const long long plane = (long long)h * w;
+  const bool vec = ((w & 3) == 0);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int y = (int)(i / groups), x0 = (int)(i - (long long)y * groups) * 4;
+    const uint8_t *p = src + (long long)y * row_stride + (long long)x0 * c;
+    const int n = min(4, w - x0);
+    using TR = OutTraits<OutT>;
+    typename TR::reg o[3][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < n) {
+        if (c == 3) {
+          o[0][k] = TR::make(p[3 * k]);
+          o[1][k] = TR::make(p[3 * k + 1]);
+          o[2][k] = TR::make(p[3 * k + 2]);
+        } else {
+          o[0][k] = o[1][k] = o[2][k] = TR::make(p[k]);
+        }
+      } else {
+        o[0][k] = o[1][k] = o[2][k] = TR::make(0);
+      }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      OutT *q = dst + ch * plane + (long long)y * w + x0;
+      if (n == 4) {
+        TR::store4(q, o[ch], vec);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < n) TR::store1(q + k, o[ch][k]);
+      }
+    }
+  }
+}
+
+int lds_pitch_for(int w, int new_w, int tw) {
+  // widest source span (pixels) a tile of `tw` output columns can touch, +1 neighbour, +alignment slack
+  double scale = (double)w / (double)new_w;
+  long span_px = (long)(scale * tw) + 3;
+  if (span_px > w) span_px = w;
+  long bytes = span_px * 3 + 15 + 15 + 12;  // alignment shift + chunk rounding + 3-dword tap window
+  return (int)((bytes + 15) & ~15L);
+}
+
+size_t lds_bytes_for(int pitch, int tw) { return (size_t)((1024 + 8 * tw + 20 * TH + 15) & ~15) + (size_t)2 * TH * pitch; }
+
+template <typename OutT>
+int launch_letterbox(const LbParams &P0, int batch, int max_pitch128, int max_pitch32, hipStream_t stream) {
+  LbParams P = P0;
+  const size_t kMaxLds = 64 * 1024;
+  if (lds_bytes_for(max_pitch128, 128) <= kMaxLds) {
+    P.pitch = max_pitch128;
+    P.tiles_x = (P.dst_w + 127) / 128;
+    P.tiles_y = (P.dst_h + TH - 1) / TH;
+    dim3 grid(P.tiles_x * P.tiles_y, batch);
+    hipLaunchKernelGGL((letterbox_kernel<OutT, 128>), grid, dim3(32 * TH), lds_bytes_for(P.pitch, 128), stream, P);
+  } else if (lds_bytes_for(max_pitch32, 32) <= 2 * kMaxLds) {
+    P.pitch = max_pitch32;
+    P.tiles_x = (P.dst_w + 31) / 32;
+    P.tiles_y = (P.dst_h + TH - 1) / TH;
+    dim3 grid(P.tiles_x * P.tiles_y, batch);
+    hipLaunchKernelGGL((letterbox_kernel<OutT, 32>), grid, dim3(8 * TH), lds_bytes_for(P.pitch, 32), stream, P);
+  } else {
+    lmi_set_error("lmi_letterbox_u8: down-scale factor too large for the LDS row tiles");
+    return LMI_ERR_LIMIT;
+  }
+  return lmi_check_launch("letterbox_kernel");
+}
+
+int check_common(const void *dst, int dst_h, int dst_w, int dst_dtype, int pad_value, int mode, int batch) {
+  LMI_REQUIRE(dst != nullptr, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: dst is NULL");
+  LMI_REQUIRE(batch > 0 && batch <= 65535, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: batch %d out of range 1..65535", batch);
+  LMI_REQUIRE(dst_h > 0 && dst_w > 0, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: bad destination size %dx%d", dst_h, dst_w);
+  LMI_REQUIRE(dst_dtype == LMI_F32 || dst_dtype == LMI_F16, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: dst_dtype must be LMI_F32 or LMI_F16");
+  LMI_REQUIRE(pad_value >= 0 && pad_value <= 255, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: pad_value %d not in 0..255", pad_value);
+  LMI_REQUIRE(mode == LMI_RESIZE_CV2_LINEAR, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: unknown resize mode %d", mode);
+  LMI_REQUIRE(lmi_is_aligned(dst, 16), LMI_ERR_ALIGNMENT, "lmi_letterbox_u8: dst must be 16-byte aligned");
+  return LMI_OK;
+}
+
+int check_frame(const void *src, int h, int w, long long stride, int new_w, int new_h, int pad_l, int pad_t, int dst_h, int dst_w, int i) {
+  LMI_REQUIRE(src != nullptr, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frame %d: src is NULL", i);
+  LMI_REQUIRE(lmi_is_aligned(src, 16), LMI_ERR_ALIGNMENT, "lmi_letterbox_u8: frame %d: src must be 16-byte aligned", i);
+  LMI_REQUIRE(h > 0 && w > 0 && stride >= 3LL * w, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frame %d: bad size/stride (%d,%d,%lld)", i, h, w, stride);
+  LMI_REQUIRE((long long)(h - 1) * stride + 3LL * w < (1LL << 32), LMI_ERR_LIMIT, "lmi_letterbox_u8: frame %d larger than 4 GiB", i);
+  LMI_REQUIRE(new_w > 0 && new_h > 0 && pad_l >= 0 && pad_t >= 0 && pad_l + new_w <= dst_w && pad_t + new_h <= dst_h,
+              LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frame %d: content %dx%d at (%d,%d) does not fit %dx%d", i, new_w, new_h, pad_l, pad_t, dst_w, dst_h);
+  return LMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, int batch, void *dst, int dst_h,
+                     int dst_w, int dst_dtype, int pad_value, int swap_rb, int mode, void *stream) {
+  int rc = check_common(dst, dst_h, dst_w, dst_dtype, pad_value, mode, batch);
+  if (rc) return rc;
+  LMI_REQUIRE(frames_host != nullptr && frames_dev != nullptr, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frames is NULL");
+  int p128 = 0, p32 = 0;
+  for (int i = 0; i < batch; ++i) {
+    const lmi_frame &f = frames_host[i];
+    rc = check_frame(reinterpret_cast<const void *>(f.src), f.h, f.w, f.row_stride, f.new_w, f.new_h, f.pad_l, f.pad_t, dst_h, dst_w, i);
+    if (rc) return rc;
+    int a = lds_pitch_for(f.w, f.new_w, 128), b = lds_pitch_for(f.w, f.new_w, 32);
+    if (a > p128) p128 = a;
+    if (b > p32) p32 = b;
+  }
+  LbParams P{};
+  P.frames = frames_dev;
+  P.dst = dst; P.dst_h = dst_h; P.dst_w = dst_w; P.pad_value = pad_value; P.swap_rb = swap_rb ? 1 : 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return dst_dtype == LMI_F32 ? launch_letterbox<float>(P, batch, p128, p32, s) : launch_letterbox<__half>(P, batch, p128, p32, s);
+}
+
+int lmi_letterbox_u8_uniform(const void *src, int batch, int h, int w, int64_t row_stride, int64_t image_stride,
+                             void *dst, int dst_h, int dst_w, int dst_dtype, int pad_value, int swap_rb, int stretch,
+                             int mode, void *stream) {
+  int rc = check_common(dst, dst_h, dst_w, dst_dtype, pad_value, mode, batch);
+  if (rc) return rc;
+  int32_t g[6];
+  rc = lmi_letterbox_geometry(h, w, dst_h, dst_w, stretch, g);
+  if (rc) return rc;
+  rc = check_frame(src, h, w, row_stride, g[0], g[1], g[2], g[4], dst_h, dst_w, 0);
+  if (rc) return rc;
+  LMI_REQUIRE(batch == 1 || (image_stride >= (int64_t)(h - 1) * row_stride + 3LL * w && (image_stride & 15) == 0),
+              batch == 1 ? LMI_ERR_BAD_ARG : LMI_ERR_ALIGNMENT,
+              "lmi_letterbox_u8_uniform: image_stride %lld must cover a frame and be a multiple of 16", (long long)image_stride);
+  LbParams P{};
+  P.frames = nullptr;
+  P.src = reinterpret_cast<const uint8_t *>(src);
+  P.h = h; P.w = w; P.row_stride = row_stride; P.image_stride = image_stride;
+  P.new_w = g[0]; P.new_h = g[1]; P.pad_l = g[2]; P.pad_t = g[4];
+  P.dst = dst; P.dst_h = dst_h; P.dst_w = dst_w; P.pad_value = pad_value; P.swap_rb = swap_rb ? 1 : 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int p128 = lds_pitch_for(w, g[0], 128), p32 = lds_pitch_for(w, g[0], 32);
+  return dst_dtype == LMI_F32 ? launch_letterbox<float>(P, batch, p128, p32, s) : launch_letterbox<__half>(P, batch, p128, p32, s);
+}
+
+int lmi_preprocess_u8(const void *src, int h, int w, int c, int64_t row_stride, void *dst, int dst_dtype, void *stream) {
+  LMI_REQUIRE(src != nullptr && dst != nullptr, LMI_ERR_BAD_ARG, "lmi_preprocess_u8: NULL pointer");
+  LMI_REQUIRE(h > 0 && w > 0 && (c == 1 || c == 3), LMI_ERR_BAD_ARG, "lmi_preprocess_u8: bad shape (%d,%d,%d); C must be 1 or 3", h, w, c);
+  LMI_REQUIRE(row_stride >= (int64_t)w * c, LMI_ERR_BAD_ARG, "lmi_preprocess_u8: row_stride %lld < %d", (long long)row_stride, w * c);
+  LMI_REQUIRE(dst_dtype == LMI_F32 || dst_dtype == LMI_F16, LMI_ERR_BAD_ARG, "lmi_preprocess_u8: dst_dtype must be LMI_F32 or LMI_F16");
+  LMI_REQUIRE(lmi_is_aligned(dst, 16), LMI_ERR_ALIGNMENT, "lmi_preprocess_u8: dst must be 16-byte aligned");
+  const long long total = (long long)h * ((w + 3) / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dst_dtype == LMI_F32)
+    hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint8_t *>(src), h, w, c, (long long)row_stride, reinterpret_cast<float *>(dst));
+  else
+    hipLaunchKernelGGL(preprocess_kernel<__half>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint8_t *>(src), h, w, c, (long long)row_stride, reinterpret_cast<__half *>(dst));
+  return lmi_check_launch("preprocess_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,308 @@
+// Segmentation mask assembly for gfx950.
+//
+// Replaces `ops.process_mask_native(proto[i], pred[:, 6:], pred[:, :4], orig_img.shape[:2])` and
+// `masks[M]` (object_detectors/yolov8_lmi/model.py:235-236; in-tree YOLOv5 analogue
+// object_detectors/yolov5_lmi/trt/yolov5_trt.py:373-415).  Semantics: oracle/masks.py.
+//
+// Kernels
+//  mask_gemm_kernel      logits[slot][y][x] = sum_k coef[slot][k] * proto[b][k][y][x] for the rows
+//                        of the letterbox crop window only, on the exact-fp32 MFMA
+//                        (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain).  A = 32 survivors x K,
+//                        B = K x 32 pixels (two 128-byte row segments per wave load), D rows are
+//                        written as 128-byte segments.  Tiny: 2*m*32*mh*mw flop per image.
+//  mask_upsample_kernel  per survivor, per strip of output rows: stages the few logits rows the
+//                        strip needs in LDS, then bilinear (align_corners=False) -> box crop ->
+//                        `> 0`, 16 bytes per lane per store.  HBM-write-bound: m*H0*W0 bytes of
+//                        uint8 per image are written exactly once (zeros outside the box included).
+#include "common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct MaskGeom {
+  int mh, mw;                    // proto size
+  int top, bottom, left, right;  // scale_masks crop window in proto space
+  int h0, w0;                    // original frame size
+};
+
+struct GemmParams {
+  const float *proto;  // (batch, 32, mh, mw)
+  const float *det;    // (batch, max_det, det_stride)
+  const int *slot_map;
+  const int *slot_base;
+  float *logits;  // (capacity, wh*mw)
+  int batch, max_det, det_stride;
+  long long capacity;
+  MaskGeom g;
+  int tiles_per_block;  // pixel tiles (32 px) per wave
+};
+
+// grid: x = pixel-tile groups, y = survivor tile (32 slots), z = image
+__global__ __launch_bounds__(256) void mask_gemm_kernel(GemmParams G) {
+  const int b = blockIdx.z;
+  const int base = G.slot_base[b];
+  const int m_b = G.slot_base[b + 1] - base;
+  const int row0 = blockIdx.y * 32;
+  if (row0 >= m_b) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wh = G.g.bottom - G.g.top;
+  const int npx = wh * G.g.mw;
+  const int plane = G.g.mh * G.g.mw;
+  const float *pb = G.proto + (size_t)b * 32 * plane + (size_t)G.g.top * G.g.mw;
+
+  // A fragments: coef[row0 + (lane&31)][2s + (lane>>5)], s = 0..15
+  float a[16];
+  {
+    const int i = row0 + (lane & 31);
+    const float *c = nullptr;
+    if (i < m_b) {
+      const int e = G.slot_map[base + i];
+      c = G.det + (size_t)e * G.det_stride + 6;
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) a[s] = c ? c[2 * s + (lane >> 5)] : 0.0f;
+  }
+
+  const int tile0 = (blockIdx.x * 4 + wave) * G.tiles_per_block;
+  for (int t = 0; t < G.tiles_per_block; ++t) {
+    const int p0 = (tile0 + t) * 32;
+    if (p0 >= npx) break;
+    const int p = p0 + (lane & 31);
+    const bool pv = p < npx;
+    floatx16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float bf[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) bf[s] = pv ? pb[(size_t)(2 * s + (lane >> 5)) * plane + p] : 0.0f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bf[s], acc, 0, 0, 0);
+    // D: col (pixel) = lane&31 ; row (survivor) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (pv) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const long long slot = (long long)base + i;
+        if (i < m_b && slot < G.capacity) G.logits[(size_t)slot * npx + p] = acc[r];
+      }
+    }
+  }
+}
+
+struct UpParams {
+  const float *det;
+  const int *slot_map;
+  const int *slot_base;
+  const float *logits;
+  void *out;
+  int batch, max_det, det_stride;
+  long long capacity;
+  MaskGeom g;
+  int rows_per_block;
+  int lds_rows;  // logits rows the LDS buffer can hold
+  int *overflow;
+};
+
+template <typename OutT>
+struct MaskOut;
+template <>
+struct MaskOut<uint8_t> {
+  static constexpr int PX = 16;
+  static __device__ __forceinline__ void store_vec(uint8_t *p, const uint32_t bits) {
+    uint4 v;
+    // expand 16 bits to 16 bytes of 0/1
+    uint32_t w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t n = (bits >> (4 * q)) & 0xfu;
+      w[q] = (n & 1u) | ((n & 2u) << 7) | ((n & 4u) << 14) | ((n & 8u) << 21);
+    }
+    v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+    *reinterpret_cast<uint4 *>(p) = v;
+  }
+  static __device__ __forceinline__ void store1(uint8_t *p, bool on) { *p = on ? 1 : 0; }
+};
+template <>
+struct MaskOut<float> {
+  static constexpr int PX = 4;
+  static __device__ __forceinline__ void store_vec(float *p, const uint32_t bits) {
+    *reinterpret_cast<float4 *>(p) = make_float4((bits & 1u) ? 1.f : 0.f, (bits & 2u) ? 1.f : 0.f, (bits & 4u) ? 1.f : 0.f, (bits & 8u) ? 1.f : 0.f);
+  }
+  static __device__ __forceinline__ void store1(float *p, bool on) { *p = on ? 1.0f : 0.0f; }
+};
+
+// aten upsample_bilinear2d, align_corners=False: source index / weights of output index d
+__device__ __forceinline__ void bilinear_src(float scale, int d, int in_n, int &i0, int &i1, float &l0, float &l1) {
+  float s = scale * ((float)d + 0.5f) - 0.5f;
+  s = fmaxf(s, 0.0f);
+  i0 = (int)s;
+  i1 = i0 + ((i0 < in_n - 1) ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.0f - l1;
+}
+
+// grid: x = row strips, y = slot
+template <typename OutT>
+__global__ __launch_bounds__(256) void mask_upsample_kernel(UpParams U) {
+  using MO = MaskOut<OutT>;
+  constexpr int PX = MO::PX;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *L = reinterpret_cast<float *>(smem);
+
+  const int total = U.slot_base[U.batch];
+  const long long slot = blockIdx.y;
+  if (slot >= total) return;
+  if (slot >= U.capacity) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && U.overflow) atomicAdd(U.overflow, 1);
+    return;
+  }
+  const int e = U.slot_map[slot];
+  const float *d = U.det + (size_t)e * U.det_stride;
+  const float bx1 = d[0], by1 = d[1], bx2 = d[2], by2 = d[3];
+  const int H0 = U.g.h0, W0 = U.g.w0;
+  const int wh = U.g.bottom - U.g.top, ww = U.g.right - U.g.left, mw = U.g.mw;
+  const float scale_h = (float)wh / (float)H0, scale_w = (float)ww / (float)W0;
+  OutT *out = reinterpret_cast<OutT *>(U.out) + (size_t)slot * H0 * W0;
+
+  const int y_begin = blockIdx.x * U.rows_per_block;
+  const int y_end = min(y_begin + U.rows_per_block, H0);
+  // rows of this strip that intersect the box: y >= by1 && y < by2
+  int ya = max(y_begin, (int)ceilf(by1));
+  int yb = min(y_end, (int)ceilf(by2));  // first integer y with y >= by2
+  const bool any = ya < yb && bx1 < bx2;
+
+  int ly_first = 0;
+  if (any) {
+    int i0, i1; float l0, l1;
+    bilinear_src(scale_h, ya, wh, i0, i1, l0, l1);
+    ly_first = i0;
+    int j0, j1;
+    bilinear_src(scale_h, yb - 1, wh, j0, j1, l0, l1);
+    const int nrows = j1 - ly_first + 1;  // <= U.lds_rows by construction on the host
+    const float *src = U.logits + (size_t)slot * wh * mw + (size_t)ly_first * mw + U.g.left;
+    for (int idx = threadIdx.x; idx < nrows * ww; idx += 256) {
+      const int r = idx / ww, c = idx - r * ww;
+      L[idx] = src[(size_t)r * mw + c];
+    }
+    __syncthreads();
+  }
+
+  const int chunks = (W0 + PX - 1) / PX;
+  const bool vec_ok = (W0 % PX) == 0;
+  const int nwork = (y_end - y_begin) * chunks;
+  for (int wi = threadIdx.x; wi < nwork; wi += 256) {
+    const int y = y_begin + wi / chunks;
+    const int x0 = (wi % chunks) * PX;
+    OutT *p = out + (size_t)y * W0 + x0;
+    uint32_t bits = 0;
+    const float fy = (float)y;
+    const bool row_in = any && (fy >= by1) && (fy < by2);
+    if (row_in && (float)(x0 + PX - 1) >= bx1 && (float)x0 < bx2) {
+      int iy0, iy1; float ly0, ly1;
+      bilinear_src(scale_h, y, wh, iy0, iy1, ly0, ly1);
+      const float *r0 = L + (iy0 - ly_first) * ww;
+      const float *r1 = L + (iy1 - ly_first) * ww;
+#pragma unroll 4
+      for (int k = 0; k < PX; ++k) {
+        const int x = x0 + k;
+        const float fx = (float)x;
+        if (x < W0 && fx >= bx1 && fx < bx2) {
+          int ix0, ix1; float lx0, lx1;
+          bilinear_src(scale_w, x, ww, ix0, ix1, lx0, lx1);
+          const float t0 = r0[ix0] * lx0 + r0[ix1] * lx1;
+          const float t1 = r1[ix0] * lx0 + r1[ix1] * lx1;
+          const float v = t0 * ly0 + t1 * ly1;
+          if (v > 0.0f) bits |= 1u << k;
+        }
+      }
+    }
+    if (vec_ok) {
+      MO::store_vec(p, bits);
+    } else {
+      for (int k = 0; k < PX && x0 + k < W0; ++k) MO::store1(p + k, (bits >> k) & 1u);
+    }
+  }
+}
+
+void crop_window(int mh, int mw, int h0, int w0, MaskGeom &g) {
+  // ultralytics scale_masks: gain = min(mh/h0, mw/w0); pad = (mw - w0*gain)/2, (mh - h0*gain)/2;
+  // top,left = int(pad_y), int(pad_x); bottom,right = int(mh - pad_y), int(mw - pad_x)
+  const double gh = (double)mh / (double)h0, gw = (double)mw / (double)w0;
+  const double gain = gh < gw ? gh : gw;
+  const double pad_x = ((double)mw - (double)w0 * gain) / 2.0;
+  const double pad_y = ((double)mh - (double)h0 * gain) / 2.0;
+  g.mh = mh; g.mw = mw; g.h0 = h0; g.w0 = w0;
+  g.top = (int)pad_y; g.left = (int)pad_x;
+  g.bottom = (int)((double)mh - pad_y); g.right = (int)((double)mw - pad_x);
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+int64_t lmi_mask_workspace_bytes(int64_t capacity_masks, int mh, int mw) {
+  if (capacity_masks <= 0 || mh <= 0 || mw <= 0) return 0;
+  return (int64_t)align_up((size_t)capacity_masks * mh * mw * sizeof(float), 256);
+}
+
+int lmi_process_mask(const float *proto, int batch, int nm, int mh, int mw, const float *det, int max_det,
+                     int det_stride, const int32_t *slot_map, const int32_t *slot_base, int h0, int w0,
+                     void *out_masks, int out_dtype, int64_t capacity_masks, int32_t *overflow, void *workspace,
+                     int64_t workspace_bytes, void *stream) {
+  LMI_REQUIRE(proto && det && slot_map && slot_base && out_masks && workspace, LMI_ERR_BAD_ARG, "lmi_process_mask: NULL pointer");
+  LMI_REQUIRE(nm == LMI_MAX_MASK_DIM, LMI_ERR_LIMIT, "lmi_process_mask: nm=%d, only %d prototype channels are supported", nm, LMI_MAX_MASK_DIM);
+  LMI_REQUIRE(batch > 0 && batch <= 65535 && mh > 0 && mw > 0 && h0 > 0 && w0 > 0 && max_det > 0 && det_stride >= 6 + nm, LMI_ERR_BAD_ARG,
+              "lmi_process_mask: bad shape batch=%d proto=%dx%d orig=%dx%d max_det=%d det_stride=%d", batch, mh, mw, h0, w0, max_det, det_stride);
+  LMI_REQUIRE(out_dtype == LMI_U8 || out_dtype == LMI_F32, LMI_ERR_BAD_ARG, "lmi_process_mask: out_dtype must be LMI_U8 or LMI_F32");
+  LMI_REQUIRE(capacity_masks > 0 && capacity_masks <= 65535, LMI_ERR_LIMIT, "lmi_process_mask: capacity_masks %lld not in 1..65535", (long long)capacity_masks);
+  LMI_REQUIRE(lmi_is_aligned(out_masks, 16) && lmi_is_aligned(workspace, 256) && lmi_is_aligned(proto, 4), LMI_ERR_ALIGNMENT,
+              "lmi_process_mask: out_masks must be 16-byte and workspace 256-byte aligned");
+  LMI_REQUIRE(workspace_bytes >= lmi_mask_workspace_bytes(capacity_masks, mh, mw), LMI_ERR_WORKSPACE, "lmi_process_mask: workspace %lld < %lld bytes",
+              (long long)workspace_bytes, (long long)lmi_mask_workspace_bytes(capacity_masks, mh, mw));
+  MaskGeom g;
+  crop_window(mh, mw, h0, w0, g);
+  const int wh = g.bottom - g.top, ww = g.right - g.left;
+  LMI_REQUIRE(wh > 0 && ww > 0 && g.top >= 0 && g.left >= 0 && g.bottom <= mh && g.right <= mw, LMI_ERR_BAD_ARG, "lmi_process_mask: empty crop window");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+
+  if (overflow) {
+    hipError_t e = hipMemsetAsync(overflow, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) { lmi_set_error("lmi_process_mask: hipMemsetAsync: %s", hipGetErrorString(e)); return LMI_ERR_LAUNCH; }
+  }
+
+  GemmParams G;
+  G.proto = proto; G.det = det; G.slot_map = slot_map; G.slot_base = slot_base; G.logits = reinterpret_cast<float *>(workspace);
+  G.batch = batch; G.max_det = max_det; G.det_stride = det_stride; G.capacity = capacity_masks; G.g = g;
+  const int npx = wh * mw;
+  const int ntiles = (npx + 31) / 32;
+  G.tiles_per_block = 4;
+  const int gx = (ntiles + 4 * G.tiles_per_block - 1) / (4 * G.tiles_per_block);
+  dim3 ggrid(gx, (max_det + 31) / 32, batch);
+  hipLaunchKernelGGL(mask_gemm_kernel, ggrid, dim3(256), 0, s, G);
+  int rc = lmi_check_launch("mask_gemm_kernel");
+  if (rc) return rc;
+
+  UpParams U;
+  U.det = det; U.slot_map = slot_map; U.slot_base = slot_base; U.logits = G.logits; U.out = out_masks;
+  U.batch = batch; U.max_det = max_det; U.det_stride = det_stride; U.capacity = capacity_masks; U.g = g; U.overflow = overflow;
+  // rows per strip: as many as keep the staged logits rows within 48 KiB of LDS
+  int rpb = 16;
+  int lds_rows = 0;
+  for (;; rpb >>= 1) {
+    lds_rows = (int)((double)rpb * (double)wh / (double)h0) + 3;
+    if (lds_rows > wh) lds_rows = wh;
+    if ((size_t)lds_rows * ww * sizeof(float) <= 48 * 1024 || rpb == 1) break;
+  }
+  LMI_REQUIRE((size_t)lds_rows * ww * sizeof(float) <= 64 * 1024, LMI_ERR_LIMIT, "lmi_process_mask: prototype rows too wide for LDS (%d)", ww);
+  U.rows_per_block = rpb; U.lds_rows = lds_rows;
+  const size_t lds = (size_t)lds_rows * ww * sizeof(float);
+  dim3 ugrid((h0 + rpb - 1) / rpb, (unsigned)capacity_masks);
+  if (out_dtype == LMI_U8)
+    hipLaunchKernelGGL(mask_upsample_kernel<uint8_t>, ugrid, dim3(256), lds, s, U);
+  else
+    hipLaunchKernelGGL(mask_upsample_kernel<float>, ugrid, dim3(256), lds, s, U);
+  return lmi_check_launch("mask_upsample_kernel");
+}
+
+}  // extern "C"

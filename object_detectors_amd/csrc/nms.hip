@@ -1,0 +1,488 @@
+// YOLOv8 non-max suppression + detection finalisation for gfx950.
+//
+// Replaces `ops.non_max_suppression` as called at object_detectors/yolov8_lmi/model.py:212 (in-tree
+// YOLOv5 analogue object_detectors/yolov5_lmi/trt/yolov5_trt.py:172-282, torchvision nms :267),
+// `ops.scale_boxes` + clip (model.py:222; yolov5_trt.py:316-341) and the per-class confidence
+// filter (model.py:223-232).  Semantics: oracle/nms.py, oracle/boxes.py.
+//
+// Kernels
+//  nms_decode_filter  grid (anchor tiles, batch): streams the nc class rows of the head once with
+//                     128-bit loads (HBM-bound, nc*A*4 bytes/image), class-max / first-argmax per
+//                     anchor, strict fp32 `> conf`, wave-ballot compaction of (score, anchor) keys.
+//  nms_sort_suppress  one 1024-lane workgroup per image (latency-bound, LDS-resident): bitonic
+//                     sort of the 64-bit keys (score desc, anchor asc = torchvision's stable
+//                     order), then greedy NMS in 64-candidate chunks: every wave tests the chunk
+//                     against the kept boxes held in LDS, pair masks inside the chunk come from
+//                     wave ballots, one wave resolves the chunk serially with readlane.  Stops
+//                     after max_det keeps (later candidates cannot change earlier keeps).
+//  finalize_kernel    one workgroup: scale/clip boxes in place, per-class threshold, dense ranks.
+#include <cmath>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kSortThreads = 1024;
+constexpr int kSortLdsCap = 16384;  // keys that fit the LDS sort buffer
+
+__host__ __device__ inline int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// float -> uint32 whose unsigned order equals the float order
+__device__ __forceinline__ uint32_t f2sortable(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float sortable2f(uint32_t s) {
+  uint32_t u = (s & 0x80000000u) ? (s & 0x7fffffffu) : ~s;
+  return __uint_as_float(u);
+}
+
+struct NmsLayout {
+  size_t off_count, off_keys, off_cls, off_sbox, total;
+  int P;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+NmsLayout nms_layout(int batch, int anchors) {
+  NmsLayout L;
+  L.P = next_pow2(anchors);
+  size_t o = 0;
+  L.off_count = o; o = align_up(o + sizeof(int) * (size_t)batch, 256);
+  L.off_keys = o;  o = align_up(o + sizeof(uint64_t) * (size_t)batch * L.P, 256);
+  L.off_cls = o;   o = align_up(o + sizeof(int) * (size_t)batch * anchors, 256);
+  L.off_sbox = o;  o = align_up(o + sizeof(float4) * (size_t)batch * anchors, 256);
+  L.total = o;
+  return L;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void nms_decode_filter(const float *__restrict__ pred, int nc, int nm, int A, float conf,
+                                                        uint64_t *__restrict__ keys, int P, int *__restrict__ cls_of,
+                                                        int *__restrict__ cand_count) {
+  const int b = blockIdx.y;
+  const int a0 = (blockIdx.x * 256 + threadIdx.x) * VEC;
+  const int C = 4 + nc + nm;
+  const float *cls = pred + ((size_t)b * C + 4) * A;
+  float best[VEC];
+  int bi[VEC];
+  bool valid = a0 < A;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+  if (valid) {
+    if constexpr (VEC == 4) {
+      float4 v = *reinterpret_cast<const float4 *>(cls + a0);
+      best[0] = v.x; best[1] = v.y; best[2] = v.z; best[3] = v.w;
+#pragma unroll 8
+      for (int c = 1; c < nc; ++c) {
+        v = *reinterpret_cast<const float4 *>(cls + (size_t)c * A + a0);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (e[k] > best[k]) { best[k] = e[k]; bi[k] = c; }
+      }
+    } else {
+      best[0] = cls[a0];
+#pragma unroll 8
+      for (int c = 1; c < nc; ++c) {
+        const float e = cls[(size_t)c * A + a0];
+        if (e > best[0]) { best[0] = e; bi[0] = c; }
+      }
+    }
+  }
+  int cnt = 0;
+  bool flag[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    flag[k] = valid && (a0 + k < A) && (best[k] > conf);
+    cnt += flag[k] ? 1 : 0;
+  }
+  // wave-level exclusive scan of cnt
+  const int lane = threadIdx.x & 63;
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  const int total = __shfl(incl, 63);
+  if (total == 0) return;
+  int base = 0;
+  if (lane == 63) base = atomicAdd(cand_count + b, total);
+  base = __shfl(base, 63);
+  int o = base + incl - cnt;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    if (flag[k]) {
+      const uint32_t anchor = (uint32_t)(a0 + k);
+      keys[(size_t)b * P + o] = ((uint64_t)f2sortable(best[k]) << 32) | (uint64_t)(~anchor);
+      cls_of[(size_t)b * A + anchor] = bi[k];
+      ++o;
+    }
+  }
+}
+
+// descending bitonic sort of P2 (power of two) keys; all kSortThreads lanes participate
+template <typename KeyPtr>
+__device__ __forceinline__ void bitonic_desc(KeyPtr a, int P2) {
+  const int tid = threadIdx.x;
+  for (int k = 2; k <= P2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (P2 >> 1); t += kSortThreads) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int p = i | j;
+        const uint64_t x = a[i], y = a[p];
+        const bool desc = (i & k) == 0;
+        if (desc ? (x < y) : (x > y)) { a[i] = y; a[p] = x; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay2, float aarea, float bx1, float by1,
+                                       float bx2, float by2, float barea, float thr) {
+  const float xx1 = fmaxf(ax1, bx1), yy1 = fmaxf(ay1, by1);
+  const float xx2 = fminf(ax2, bx2), yy2 = fminf(ay2, by2);
+  const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+  const float inter = w * h;
+  if (!(inter > 0.0f)) return false;  // 0/x and 0/0 never exceed a threshold >= 0
+  const float ovr = inter / (aarea + barea - inter);
+  return ovr > thr;
+}
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int srclane) {
+  const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, srclane);
+  const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), srclane);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+struct SortNmsParams {
+  const float *pred;
+  int nc, nm, A;
+  float iou_thr;  // effective fp32 threshold (see host side)
+  int agnostic, max_det, max_nms;
+  float max_wh;
+  uint64_t *keys;
+  int P;
+  const int *cls_of;
+  float4 *sbox;
+  const int *cand_count;
+  float *out_det;
+  int *out_count;
+  int *out_anchor;
+  int lds_keys;  // capacity (keys) of the LDS sort buffer
+};
+
+__global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t *lkeys = reinterpret_cast<uint64_t *>(smem);
+  const int md = (S.max_det + 1) & ~1;  // even stride keeps the 64-bit arrays behind it 8-byte aligned
+  float *kx1 = reinterpret_cast<float *>(smem + (size_t)S.lds_keys * 8);
+  float *ky1 = kx1 + md;
+  float *kx2 = ky1 + md;
+  float *ky2 = kx2 + md;
+  float *karea = ky2 + md;
+  int *kpos = reinterpret_cast<int *>(karea + md);
+  uint64_t *pairmask = reinterpret_cast<uint64_t *>(kpos + md);
+  int *supp = reinterpret_cast<int *>(pairmask + 64);
+  int *sK = supp + 64;
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int A = S.A, C = 4 + S.nc + S.nm;
+  const float *pb = S.pred + (size_t)b * C * A;
+  uint64_t *gkeys = S.keys + (size_t)b * S.P;
+  float4 *sbox = S.sbox + (size_t)b * A;
+
+  const int n = min(S.cand_count[b], A);
+  if (n == 0) {
+    if (tid == 0) S.out_count[b] = 0;
+    return;
+  }
+  const int P2 = next_pow2(n);
+  const bool in_lds = P2 <= S.lds_keys;
+
+  // ---- sort -------------------------------------------------------------------------------------
+  if (in_lds) {
+    for (int i = tid; i < P2; i += kSortThreads) lkeys[i] = (i < n) ? gkeys[i] : 0ull;
+    __syncthreads();
+    bitonic_desc(lkeys, P2);
+  } else {
+    for (int i = n + tid; i < P2; i += kSortThreads) gkeys[i] = 0ull;
+    __syncthreads();
+    bitonic_desc(gkeys, P2);
+  }
+  const int n_eff = min(n, S.max_nms);
+
+  // ---- decode the sorted candidates' (class-offset) boxes ------------------------------------------
+  for (int i = tid; i < n_eff; i += kSortThreads) {
+    const uint64_t key = in_lds ? lkeys[i] : gkeys[i];
+    const uint32_t anchor = ~(uint32_t)key;
+    const float cx = pb[anchor], cy = pb[(size_t)A + anchor], w = pb[(size_t)2 * A + anchor], h = pb[(size_t)3 * A + anchor];
+    const float hw = w / 2.0f, hh = h / 2.0f;
+    const float c = S.agnostic ? 0.0f : (float)S.cls_of[(size_t)b * A + anchor] * S.max_wh;
+    sbox[i] = make_float4((cx - hw) + c, (cy - hh) + c, (cx + hw) + c, (cy + hh) + c);
+  }
+  if (tid < 64) supp[tid] = 0;
+  if (tid == 0) *sK = 0;
+  __syncthreads();
+
+  // ---- greedy NMS in chunks of 64 sorted candidates ---------------------------------------------
+  int K = 0;
+  for (int base = 0; base < n_eff && K < S.max_det; base += 64) {
+    const int m = min(64, n_eff - base);
+    float4 cb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < m) cb = sbox[base + lane];
+    const float carea = (cb.z - cb.x) * (cb.w - cb.y);
+
+    // A: chunk vs kept boxes, kept index strided over the 16 waves
+    bool hit = false;
+    for (int k = wave; k < K; k += kSortThreads / 64)
+      hit = hit || iou_gt(kx1[k], ky1[k], kx2[k], ky2[k], karea[k], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
+    if (hit && lane < m) supp[lane] = 1;
+
+    // B: pair masks inside the chunk: row j = lanes i > j that j would suppress
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = wave * 4 + q;  // wave-uniform
+      const float jx1 = __shfl(cb.x, j), jy1 = __shfl(cb.y, j), jx2 = __shfl(cb.z, j), jy2 = __shfl(cb.w, j);
+      const float jarea = __shfl(carea, j);
+      const bool p = (lane > j) && (lane < m) && (j < m) && iou_gt(jx1, jy1, jx2, jy2, jarea, cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
+      const uint64_t mask = __ballot(p);
+      if (lane == 0) pairmask[j] = mask;
+    }
+    __syncthreads();
+
+    if (wave == 0) {
+      uint64_t alive = __ballot(lane < m && supp[lane] == 0);
+      const uint64_t pm = pairmask[lane];
+      uint64_t keepm = 0;
+      int Kl = K;
+      while (alive != 0 && Kl < S.max_det) {
+        const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(alive));
+        keepm |= 1ull << j;
+        ++Kl;
+        alive &= ~readlane_u64(pm, j);
+        alive &= ~(1ull << j);
+      }
+      if ((keepm >> lane) & 1ull) {
+        const int idx = K + __builtin_popcountll(keepm & ((1ull << lane) - 1ull));
+        kx1[idx] = cb.x; ky1[idx] = cb.y; kx2[idx] = cb.z; ky2[idx] = cb.w;
+        karea[idx] = carea;
+        kpos[idx] = base + lane;
+      }
+      supp[lane] = 0;
+      if (lane == 0) *sK = Kl;
+    }
+    __syncthreads();
+    K = *sK;
+  }
+
+  // ---- emit rows: x1,y1,x2,y2 (no class offset), conf, cls, coef... ---------------------------------
+  if (tid == 0) S.out_count[b] = K;
+  const int row = 6 + S.nm;
+  float *od = S.out_det + (size_t)b * S.max_det * row;
+  for (int e = tid; e < K * row; e += kSortThreads) {
+    const int t = e / row, col = e - t * row;
+    const int pos = kpos[t];
+    const uint64_t key = in_lds ? lkeys[pos] : gkeys[pos];
+    const uint32_t anchor = ~(uint32_t)key;
+    float v;
+    if (col < 4) {
+      const float c0 = pb[(size_t)(col & 1) * A + anchor];
+      const float half = pb[(size_t)(2 + (col & 1)) * A + anchor] / 2.0f;
+      v = (col < 2) ? (c0 - half) : (c0 + half);
+    } else if (col == 4) {
+      v = sortable2f((uint32_t)(key >> 32));
+    } else if (col == 5) {
+      v = (float)S.cls_of[(size_t)b * A + anchor];
+    } else {
+      v = pb[(size_t)(4 + S.nc + (col - 6)) * A + anchor];
+    }
+    od[e] = v;
+    if (col == 0) S.out_anchor[(size_t)b * S.max_det + t] = (int)anchor;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct FinalizeParams {
+  float *det;
+  const int *count;
+  int batch, max_det, det_stride, nc;
+  int model_h, model_w;
+  const int *orig_hw;
+  int uh0, uw0;
+  int pad_round;
+  const double *thres;
+  double uniform_thres;
+  uint8_t *keep;
+  int *keep_count;
+  int *mask_slot;
+  int *slot_map;
+  int *slot_base;
+};
+
+// Python round(): nearest, ties to even
+__device__ __forceinline__ double py_round(double x) { return rint(x); }
+
+__global__ __launch_bounds__(1024) void finalize_kernel(FinalizeParams F) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int *m_cnt = reinterpret_cast<int *>(smem);        // batch
+  int *m_base = m_cnt + F.batch;                      // batch
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+
+  // one wave per image: boxes, keep flags, in-image ranks
+  for (int b = wave; b < F.batch; b += nwaves) {
+    const int n = min(F.count[b], F.max_det);
+    const int h0 = F.orig_hw ? F.orig_hw[2 * b] : F.uh0;
+    const int w0 = F.orig_hw ? F.orig_hw[2 * b + 1] : F.uw0;
+    // ops.scale_boxes: gain / pad in double (Python floats), applied in fp32
+    const double gh = (double)F.model_h / (double)h0, gw = (double)F.model_w / (double)w0;
+    const double gain = gh < gw ? gh : gw;
+    double px = ((double)F.model_w - (double)w0 * gain) / 2.0;
+    double py = ((double)F.model_h - (double)h0 * gain) / 2.0;
+    if (F.pad_round) { px = py_round(px - 0.1); py = py_round(py - 0.1); }
+    const float fpx = (float)px, fpy = (float)py, fgain = (float)gain;
+    const float fw0 = (float)w0, fh0 = (float)h0;
+    int kept = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + lane;
+      bool k = false;
+      if (i < n) {
+        float *d = F.det + ((size_t)b * F.max_det + i) * F.det_stride;
+        float x1 = d[0], y1 = d[1], x2 = d[2], y2 = d[3];
+        x1 = (x1 - fpx) / fgain; y1 = (y1 - fpy) / fgain;
+        x2 = (x2 - fpx) / fgain; y2 = (y2 - fpy) / fgain;
+        d[0] = fminf(fmaxf(x1, 0.0f), fw0);
+        d[1] = fminf(fmaxf(y1, 0.0f), fh0);
+        d[2] = fminf(fmaxf(x2, 0.0f), fw0);
+        d[3] = fminf(fmaxf(y2, 0.0f), fh0);
+        const float conf = d[4];
+        const int c = (int)d[5];
+        const double t = F.thres ? ((c >= 0 && c < F.nc) ? F.thres[c] : 1.0) : F.uniform_thres;
+        k = (double)conf > t;
+        F.keep[(size_t)b * F.max_det + i] = k ? 1 : 0;
+      }
+      const uint64_t mask = __ballot(k);
+      if (i < n && F.mask_slot)
+        F.mask_slot[(size_t)b * F.max_det + i] = k ? kept + __builtin_popcountll(mask & ((1ull << lane) - 1ull)) : -1;
+      kept += __builtin_popcountll(mask);
+    }
+    // rows beyond count: not kept
+    for (int i = n + lane; i < F.max_det; i += 64) {
+      F.keep[(size_t)b * F.max_det + i] = 0;
+      if (F.mask_slot) F.mask_slot[(size_t)b * F.max_det + i] = -1;
+    }
+    if (lane == 0) { m_cnt[b] = kept; F.keep_count[b] = kept; }
+  }
+  __syncthreads();
+  // exclusive scan over images (serial: batch is small)
+  if (tid == 0) {
+    int s = 0;
+    for (int b = 0; b < F.batch; ++b) {
+      m_base[b] = s;
+      if (F.slot_base) F.slot_base[b] = s;
+      s += m_cnt[b];
+    }
+    if (F.slot_base) F.slot_base[F.batch] = s;
+  }
+  __syncthreads();
+  if (F.mask_slot) {
+    for (int e = tid; e < F.batch * F.max_det; e += blockDim.x) {
+      const int b = e / F.max_det;
+      const int r = F.mask_slot[e];
+      if (r >= 0) {
+        const int slot = m_base[b] + r;
+        F.mask_slot[e] = slot;
+        if (F.slot_map) F.slot_map[slot] = e;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t lmi_nms_workspace_bytes(int batch, int anchors) {
+  if (batch <= 0 || anchors <= 0) return 0;
+  return (int64_t)nms_layout(batch, anchors).total;
+}
+
+int lmi_nms_v8(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres, double iou_thres,
+               int agnostic, int max_det, int max_nms, float max_wh, float *out_det, int32_t *out_count,
+               int32_t *out_anchor, void *workspace, int64_t workspace_bytes, void *stream) {
+  LMI_REQUIRE(pred && out_det && out_count && out_anchor && workspace, LMI_ERR_BAD_ARG, "lmi_nms_v8: NULL pointer");
+  LMI_REQUIRE(batch > 0 && batch <= 65535 && nc > 0 && nm >= 0 && anchors > 0, LMI_ERR_BAD_ARG,
+              "lmi_nms_v8: bad shape batch=%d nc=%d nm=%d anchors=%d", batch, nc, nm, anchors);
+  LMI_REQUIRE(anchors <= (1 << 24), LMI_ERR_LIMIT, "lmi_nms_v8: anchors %d > 2^24", anchors);
+  LMI_REQUIRE(max_det > 0 && max_det <= LMI_MAX_DET_CAP, LMI_ERR_LIMIT, "lmi_nms_v8: max_det %d not in 1..%d", max_det, LMI_MAX_DET_CAP);
+  LMI_REQUIRE(max_nms > 0, LMI_ERR_BAD_ARG, "lmi_nms_v8: max_nms must be positive");
+  LMI_REQUIRE(iou_thres >= 0.0 && iou_thres <= 1.0, LMI_ERR_BAD_ARG, "lmi_nms_v8: Invalid IoU %f, valid values are between 0.0 and 1.0", iou_thres);
+  LMI_REQUIRE(lmi_is_aligned(pred, 16) && lmi_is_aligned(workspace, 256) && lmi_is_aligned(out_det, 4), LMI_ERR_ALIGNMENT,
+              "lmi_nms_v8: pred must be 16-byte and workspace 256-byte aligned");
+  const NmsLayout L = nms_layout(batch, anchors);
+  LMI_REQUIRE(workspace_bytes >= (int64_t)L.total, LMI_ERR_WORKSPACE, "lmi_nms_v8: workspace %lld < %lld bytes",
+              (long long)workspace_bytes, (long long)L.total);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+  int *cand_count = reinterpret_cast<int *>(ws + L.off_count);
+  uint64_t *keys = reinterpret_cast<uint64_t *>(ws + L.off_keys);
+  int *cls_of = reinterpret_cast<int *>(ws + L.off_cls);
+  float4 *sbox = reinterpret_cast<float4 *>(ws + L.off_sbox);
+
+  hipError_t e = hipMemsetAsync(cand_count, 0, sizeof(int) * (size_t)batch, s);
+  if (e != hipSuccess) { lmi_set_error("lmi_nms_v8: hipMemsetAsync: %s", hipGetErrorString(e)); return LMI_ERR_LAUNCH; }
+
+  if ((anchors & 3) == 0) {
+    dim3 grid((anchors / 4 + 255) / 256, batch);
+    hipLaunchKernelGGL(nms_decode_filter<4>, grid, dim3(256), 0, s, pred, nc, nm, anchors, conf_thres, keys, L.P, cls_of, cand_count);
+  } else {
+    dim3 grid((anchors + 255) / 256, batch);
+    hipLaunchKernelGGL(nms_decode_filter<1>, grid, dim3(256), 0, s, pred, nc, nm, anchors, conf_thres, keys, L.P, cls_of, cand_count);
+  }
+  int rc = lmi_check_launch("nms_decode_filter");
+  if (rc) return rc;
+
+  // torchvision compares the fp32 IoU against the threshold as a double: use the largest fp32 <= thr
+  float thr = (float)iou_thres;
+  if ((double)thr > iou_thres) thr = std::nextafterf(thr, -INFINITY);
+
+  SortNmsParams S;
+  S.pred = pred; S.nc = nc; S.nm = nm; S.A = anchors; S.iou_thr = thr; S.agnostic = agnostic ? 1 : 0;
+  S.max_det = max_det; S.max_nms = max_nms; S.max_wh = max_wh; S.keys = keys; S.P = L.P; S.cls_of = cls_of;
+  S.sbox = sbox; S.cand_count = cand_count; S.out_det = out_det; S.out_count = out_count; S.out_anchor = out_anchor;
+  S.lds_keys = L.P < kSortLdsCap ? L.P : kSortLdsCap;
+  const size_t lds = (size_t)S.lds_keys * 8 + 4 * 6 * (size_t)((max_det + 1) & ~1) + 64 * 8 + 64 * 4 + 16;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_suppress), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(nms_sort_suppress, dim3(batch), dim3(kSortThreads), lds, s, S);
+  return lmi_check_launch("nms_sort_suppress");
+}
+
+int lmi_finalize_detections(float *det, const int32_t *count, int batch, int max_det, int det_stride, int nc, int model_h,
+                            int model_w, const int32_t *orig_hw, int uniform_h0, int uniform_w0, int pad_round,
+                            const double *thres, double uniform_thres, uint8_t *keep, int32_t *keep_count,
+                            int32_t *mask_slot, int32_t *slot_map, int32_t *slot_base, void *stream) {
+  LMI_REQUIRE(det && count && keep && keep_count, LMI_ERR_BAD_ARG, "lmi_finalize_detections: NULL pointer");
+  LMI_REQUIRE(batch > 0 && batch <= 8192 && max_det > 0 && det_stride >= 6 && nc > 0, LMI_ERR_BAD_ARG,
+              "lmi_finalize_detections: bad shape batch=%d max_det=%d det_stride=%d nc=%d", batch, max_det, det_stride, nc);
+  LMI_REQUIRE(model_h > 0 && model_w > 0, LMI_ERR_BAD_ARG, "lmi_finalize_detections: bad model size");
+  LMI_REQUIRE(orig_hw != nullptr || (uniform_h0 > 0 && uniform_w0 > 0), LMI_ERR_BAD_ARG, "lmi_finalize_detections: original image size missing");
+  LMI_REQUIRE(slot_map == nullptr || mask_slot != nullptr, LMI_ERR_BAD_ARG, "lmi_finalize_detections: slot_map needs mask_slot");
+  FinalizeParams F;
+  F.det = det; F.count = count; F.batch = batch; F.max_det = max_det; F.det_stride = det_stride; F.nc = nc;
+  F.model_h = model_h; F.model_w = model_w; F.orig_hw = orig_hw; F.uh0 = uniform_h0; F.uw0 = uniform_w0;
+  F.pad_round = pad_round ? 1 : 0; F.thres = thres; F.uniform_thres = uniform_thres; F.keep = keep; F.keep_count = keep_count;
+  F.mask_slot = mask_slot; F.slot_map = slot_map; F.slot_base = slot_base;
+  const size_t lds = sizeof(int) * 2 * (size_t)batch + 16;
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), lds, reinterpret_cast<hipStream_t>(stream), F);
+  return lmi_check_launch("finalize_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+"""Torch-facing wrappers over the C ABI of liblmi_hip.so.
+
+PyTorch is plumbing here (device memory, streams); every computation below happens in the HIP
+kernels of `csrc/`.  All functions enqueue on the current torch stream and do not synchronise
+unless they say so.  There is no CPU fallback: tensors must live on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import LMI_F16, LMI_F32, LMI_U8, check, lmi_frame
+
+_L = _lib.load()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(t: torch.Tensor, name: str) -> None:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError(f"{name} must be a tensor on the GPU (there is no CPU fallback for this path)")
+
+
+def _dt(fp16: bool):
+    return (torch.float16, LMI_F16) if fp16 else (torch.float32, LMI_F32)
+
+
+def letterbox_geometry(h: int, w: int, dst_h: int, dst_w: int, stretch: bool = False):
+    """(new_w, new_h, pad_l, pad_r, pad_t, pad_b) -- host arithmetic only."""
+    out = (C.c_int32 * 6)()
+    check(_L.lmi_letterbox_geometry(h, w, dst_h, dst_w, 1 if stretch else 0, out))
+    return tuple(int(v) for v in out)
+
+
+def preprocess_u8(im: torch.Tensor, fp16: bool = False) -> torch.Tensor:
+    """`Yolov8.preprocess` for one uint8 image (H,W) / (H,W,1) / (H,W,3) -> (1,3,H,W)."""
+    _need_cuda(im, "im")
+    if im.dtype != torch.uint8:
+        raise TypeError("preprocess_u8 expects uint8")
+    if im.ndim == 2:
+        im = im.unsqueeze(-1)
+    h, w, c = im.shape
+    if im.stride(2) != 1 or im.stride(1) != c:
+        im = im.contiguous()
+    tdt, ldt = _dt(fp16)
+    out = torch.empty((1, 3, h, w), dtype=tdt, device=im.device)
+    check(_L.lmi_preprocess_u8(im.data_ptr(), h, w, c, im.stride(0), out.data_ptr(), ldt, _stream()))
+    return out
+
+
+def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple[int, int], pad_value: int = 114,
+              swap_rb: bool = False, fp16: bool = False, stretch: bool = False,
+              out: Optional[torch.Tensor] = None):
+    """Fused cv2-INTER_LINEAR resize + centred pad + channel swap + /255 + NCHW.
+
+    frames: a (B,H,W,3) uint8 tensor (uniform batch) or a sequence of (H,W,3) uint8 tensors of any
+    sizes.  Returns (tensor (B,3,dst_h,dst_w), operators) where operators[b] is the list
+    `[{'resize': [new_w,new_h,w,h]}, {'pad': [L,R,T,B]}]` that `revert_to_origin` consumes.
+    """
+    dst_h, dst_w = int(dst_hw[0]), int(dst_hw[1])
+    tdt, ldt = _dt(fp16)
+    if isinstance(frames, torch.Tensor):
+        _need_cuda(frames, "frames")
+        if frames.ndim == 3:
+            frames = frames.unsqueeze(0)
+        if frames.dtype != torch.uint8 or frames.shape[-1] != 3:
+            raise TypeError("letterbox expects uint8 (B,H,W,3)")
+        if frames.stride(3) != 1 or frames.stride(2) != 3 or (frames.shape[0] > 1 and frames.stride(0) % 16) or frames.data_ptr() % 16:
+            frames = frames.contiguous()
+            if frames.shape[0] > 1 and frames.stride(0) % 16:
+                return letterbox(list(frames.unbind(0)), dst_hw, pad_value, swap_rb, fp16, stretch, out)
+        b, h, w, _ = frames.shape
+        if out is None:
+            out = torch.empty((b, 3, dst_h, dst_w), dtype=tdt, device=frames.device)
+        check(_L.lmi_letterbox_u8_uniform(frames.data_ptr(), b, h, w, frames.stride(1), frames.stride(0), out.data_ptr(),
+                                          dst_h, dst_w, ldt, pad_value, int(swap_rb), int(stretch), 0, _stream()))
+        g = letterbox_geometry(h, w, dst_h, dst_w, stretch)
+        ops = [[{"resize": [g[0], g[1], w, h]}, {"pad": [g[2], g[3], g[4], g[5]]}] for _ in range(b)]
+        return out, ops
+    frames = list(frames)
+    if not frames:
+        raise ValueError("letterbox: empty batch")
+    keep = []
+    desc = (lmi_frame * len(frames))()
+    ops = []
+    for i, f in enumerate(frames):
+        _need_cuda(f, f"frames[{i}]")
+        if f.dtype != torch.uint8 or f.ndim != 3 or f.shape[-1] != 3:
+            raise TypeError("letterbox expects uint8 (H,W,3) frames")
+        if f.stride(2) != 1 or f.stride(1) != 3 or f.data_ptr() % 16:
+            f = f.contiguous()
+            if f.data_ptr() % 16:
+                f = f.clone()
+        keep.append(f)
+        h, w, _ = f.shape
+        g = letterbox_geometry(h, w, dst_h, dst_w, stretch)
+        desc[i] = lmi_frame(f.data_ptr(), h, w, f.stride(0), g[0], g[1], g[2], g[4], 0)
+        ops.append([{"resize": [g[0], g[1], w, h]}, {"pad": [g[2], g[3], g[4], g[5]]}])
+    dev = keep[0].device
+    host = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8)
+    ddev = host.to(dev)
+    if out is None:
+        out = torch.empty((len(keep), 3, dst_h, dst_w), dtype=tdt, device=dev)
+    check(_L.lmi_letterbox_u8(C.addressof(desc), ddev.data_ptr(), len(keep), out.data_ptr(), dst_h, dst_w, ldt,
+                              pad_value, int(swap_rb), 0, _stream()))
+    ddev.record_stream(torch.cuda.current_stream())
+    return out, ops
+
+
+class _WorkspaceCache:
+    """One growing byte buffer per (device, tag): the library itself never allocates."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, device: torch.device, tag: str, nbytes: int) -> torch.Tensor:
+        key = (device.index, tag)
+        t = self._buf.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=device)
+            self._buf[key] = t
+        return t
+
+
+_ws = _WorkspaceCache()
+
+
+def nms_v8(pred: torch.Tensor, conf_thres: float, iou_thres: float = 0.45, agnostic: bool = False, max_det: int = 300,
+           nc: int = 0, max_nms: int = 30000, max_wh: float = 7680.0):
+    """`ops.non_max_suppression` on the head output (B, 4+nc+nm, A) fp32.
+
+    Returns (det (B,max_det,6+nm) fp32, count (B,) int32, anchor (B,max_det) int32), all on the
+    device; rows >= count[b] are unspecified."""
+    _need_cuda(pred, "pred")
+    if pred.dtype != torch.float32:
+        pred = pred.float()
+    if not pred.is_contiguous():
+        pred = pred.contiguous()
+    b, ch, a = pred.shape
+    nc = nc or (ch - 4)
+    nm = ch - nc - 4
+    if nm < 0:
+        raise ValueError(f"nc={nc} does not fit a head with {ch} channels")
+    det = torch.empty((b, max_det, 6 + nm), dtype=torch.float32, device=pred.device)
+    count = torch.empty((b,), dtype=torch.int32, device=pred.device)
+    anchor = torch.empty((b, max_det), dtype=torch.int32, device=pred.device)
+    nbytes = int(_L.lmi_nms_workspace_bytes(b, a))
+    ws = _ws.get(pred.device, "nms", nbytes)
+    check(_L.lmi_nms_v8(pred.data_ptr(), b, nc, nm, a, float(conf_thres), float(iou_thres), int(agnostic), int(max_det),
+                        int(max_nms), float(max_wh), det.data_ptr(), count.data_ptr(), anchor.data_ptr(), ws.data_ptr(),
+                        ws.numel(), _stream()))
+    return det, count, anchor
+
+
+def finalize_detections(det: torch.Tensor, count: torch.Tensor, nc: int, model_hw: Tuple[int, int],
+                        orig_hw: Union[Tuple[int, int], torch.Tensor], thres: Union[float, torch.Tensor],
+                        pad_round: bool = True, with_slots: bool = True):
+    """scale_boxes + clip IN PLACE on det[..., :4], per-class threshold, dense survivor ranks.
+
+    orig_hw: (H0, W0) for every image, or an int32 device tensor (B,2).  thres: a float, or a
+    float64 device tensor (nc,) of per-class thresholds.
+    Returns dict(keep (B,max_det) uint8, keep_count (B,), mask_slot, slot_map, slot_base (B+1,))."""
+    _need_cuda(det, "det")
+    b, max_det, stride = det.shape
+    dev = det.device
+    keep = torch.empty((b, max_det), dtype=torch.uint8, device=dev)
+    keep_count = torch.empty((b,), dtype=torch.int32, device=dev)
+    mask_slot = torch.empty((b, max_det), dtype=torch.int32, device=dev) if with_slots else None
+    slot_map = torch.empty((b * max_det,), dtype=torch.int32, device=dev) if with_slots else None
+    slot_base = torch.empty((b + 1,), dtype=torch.int32, device=dev) if with_slots else None
+    if isinstance(orig_hw, torch.Tensor):
+        _need_cuda(orig_hw, "orig_hw")
+        ohw = orig_hw.to(torch.int32).contiguous()
+        ohw_ptr, uh, uw = ohw.data_ptr(), 0, 0
+    else:
+        ohw, ohw_ptr, uh, uw = None, None, int(orig_hw[0]), int(orig_hw[1])
+    if isinstance(thres, torch.Tensor):
+        _need_cuda(thres, "thres")
+        th = thres.to(torch.float64).contiguous()
+        if th.numel() != nc:
+            raise ValueError("per-class thresholds must have nc entries")
+        th_ptr, ut = th.data_ptr(), 0.0
+    else:
+        th, th_ptr, ut = None, None, float(thres)
+    p = lambda t: t.data_ptr() if t is not None else None
+    check(_L.lmi_finalize_detections(det.data_ptr(), count.data_ptr(), b, max_det, stride, nc, int(model_hw[0]),
+                                     int(model_hw[1]), ohw_ptr, uh, uw, int(pad_round), th_ptr, ut, keep.data_ptr(),
+                                     keep_count.data_ptr(), p(mask_slot), p(slot_map), p(slot_base), _stream()))
+    return {"keep": keep, "keep_count": keep_count, "mask_slot": mask_slot, "slot_map": slot_map, "slot_base": slot_base}
+
+
+def process_mask(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.Tensor, slot_base: torch.Tensor,
+                 orig_hw: Tuple[int, int], capacity: int, out_dtype: torch.dtype = torch.uint8,
+                 out: Optional[torch.Tensor] = None):
+    """`process_mask_native` + `masks[M]` for the whole batch (uniform original size).
+
+    Returns (masks (capacity,H0,W0) of uint8|float32 in slot order, overflow (1,) int32)."""
+    _need_cuda(proto, "proto")
+    if proto.dtype != torch.float32:
+        proto = proto.float()
+    if not proto.is_contiguous():
+        proto = proto.contiguous()
+    b, nm, mh, mw = proto.shape
+    _, max_det, stride = det.shape
+    h0, w0 = int(orig_hw[0]), int(orig_hw[1])
+    ldt = {torch.uint8: LMI_U8, torch.float32: LMI_F32}[out_dtype]
+    capacity = max(int(capacity), 1)
+    if out is None:
+        out = torch.empty((capacity, h0, w0), dtype=out_dtype, device=proto.device)
+    overflow = torch.empty((1,), dtype=torch.int32, device=proto.device)
+    nbytes = int(_L.lmi_mask_workspace_bytes(capacity, mh, mw))
+    ws = _ws.get(proto.device, "mask", nbytes)
+    check(_L.lmi_process_mask(proto.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
+                              slot_base.data_ptr(), h0, w0, out.data_ptr(), ldt, capacity, overflow.data_ptr(),
+                              ws.data_ptr(), ws.numel(), _stream()))
+    return out, overflow
