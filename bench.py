@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- pre+post images/sec of the YOLOv8 path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident
+in HBM: letterbox(64 x 1080p frames) -> NMS(head) -> scale/clip/threshold -> process_mask(proto).
+The network forward is excluded (it is not part of the pre+post metric); `segments` are not
+computed (return_segments=False).  Weak scaling: every rank processes its own batch per step, with
+no collective inside the timed region; RCCL only reduces the timings / counters afterwards.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see the keys below); diagnostics go to stderr.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (batch, frame_h, frame_w, model size, nc, nm, objects/img, description)
+    "seg640": dict(batch=64, h=1080, w=1920, size=640, nc=80, nm=32, objects=40,
+                   desc="YOLOv8-seg 640 bs64, synthetic 1080p frames, head (64,116,8400), proto (64,32,160,160)"),
+    "det640": dict(batch=64, h=1080, w=1920, size=640, nc=80, nm=0, objects=40,
+                   desc="YOLOv8s detect 640 bs64, synthetic 1080p frames, head (64,84,8400)"),
+    "seg1280": dict(batch=32, h=1080, w=1920, size=1280, nc=80, nm=32, objects=60,
+                    desc="YOLOv8x-seg 1280 bs32, synthetic 1080p frames, head (32,116,33600), proto (32,32,320,320)"),
+    "det640_4k": dict(batch=64, h=2160, w=3840, size=640, nc=80, nm=0, objects=40,
+                      desc="YOLOv8m detect 640, synthetic 4K frames, 64 per step per GPU"),
+}
+CONF, IOU, MAX_DET, MASK_CONF = 0.25, 0.45, 300, 0.25
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_inputs(cfg, seed, device):
+    from object_detectors_amd import synth
+    rng = np.random.default_rng(seed)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    frames = torch.randint(0, 256, (cfg["batch"], cfg["h"], cfg["w"], 3), dtype=torch.uint8, device=device, generator=g)
+    head = torch.from_numpy(synth.head(rng, cfg["batch"], cfg["nc"], cfg["nm"], cfg["size"], cfg["objects"])).to(device)
+    proto = None
+    if cfg["nm"]:
+        proto = torch.from_numpy(synth.proto(rng, cfg["batch"], cfg["nm"], cfg["size"] // 4, cfg["size"] // 4)).to(device)
+    return frames, head, proto
+
+
+class Pipeline:
+    """The hot path on one GPU, with every output buffer preallocated after the first pass."""
+
+    def __init__(self, cfg, frames, head, proto):
+        from object_detectors_amd import hip_ops
+        self.ops, self.cfg = hip_ops, cfg
+        self.frames, self.head, self.proto = frames, head, proto
+        self.S = cfg["size"]
+        self.lb_out = torch.empty((cfg["batch"], 3, self.S, self.S), dtype=torch.float32, device=frames.device)
+        self.mask_out = None
+        self.capacity = 0
+        self.ev = None
+
+    def step(self, time_upsample=None):
+        ops, cfg = self.ops, self.cfg
+        ops.letterbox(self.frames, (self.S, self.S), pad_value=114, swap_rb=True, out=self.lb_out)
+        det, count, anchor = ops.nms_v8(self.head, CONF, IOU, nc=cfg["nc"], max_det=MAX_DET)
+        fin = ops.finalize_detections(det, count, cfg["nc"], (self.S, self.S), (cfg["h"], cfg["w"]), MASK_CONF)
+        masks = None
+        if self.proto is not None:
+            if self.mask_out is None:  # first pass: size the mask buffer from the (deterministic) survivor count
+                self.capacity = int(fin["slot_base"][-1].item())
+                self.mask_out = torch.empty((max(self.capacity, 1), cfg["h"], cfg["w"]), dtype=torch.uint8, device=self.frames.device)
+            masks, ovf = ops.process_mask(self.proto, det, fin["slot_map"], fin["slot_base"], (cfg["h"], cfg["w"]),
+                                          self.capacity, torch.uint8, out=self.mask_out, split_events=time_upsample)
+        return det, count, anchor, fin, masks
+
+
+def cpu_baseline(cfg, frames, head, proto, n_img, threads):
+    """The oracle (CPU restatement of the reference path) on the first n_img images of the workload."""
+    from oracle import boxes as OB, cv2_resize as OC, masks as OM, nms as ON
+    torch.set_num_threads(threads)
+    f = frames[:n_img].cpu().numpy()
+    p = head[:n_img].cpu().numpy()
+    pr = proto[:n_img].cpu().numpy() if proto is not None else None
+    S = cfg["size"]
+    t0 = time.perf_counter()
+    ndet = 0
+    for i in range(n_img):
+        OC.letterbox_u8(f[i], S, S, pad_value=114, swap_rb=True)
+        (det, _), = ON.non_max_suppression(p[i:i + 1], CONF, IOU, nc=cfg["nc"], max_det=MAX_DET)
+        if len(det):
+            boxes = OB.scale_boxes((S, S), det[:, :4], (cfg["h"], cfg["w"], 3))
+            M = OB.class_filter(det[:, 4], det[:, 5], np.full(cfg["nc"], MASK_CONF))
+            if pr is not None:
+                m = OM.process_mask_native(pr[i], det[:, 6:], boxes, (cfg["h"], cfg["w"]))[M]
+                m = m.astype(np.uint8)
+            ndet += int(M.sum())
+    dt = time.perf_counter() - t0
+    return n_img / dt, dt, ndet
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="seg640", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-images", type=int, default=8, help="images of the workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--seed", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run for N>1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    cfg = WORKLOADS[args.workload]
+    t_gen = time.perf_counter()
+    frames, head, proto = make_inputs(cfg, args.seed + 1000 * rank, device)
+    pipe = Pipeline(cfg, frames, head, proto)
+    log(f"[bench r{rank}] inputs ready in {time.perf_counter() - t_gen:.1f}s: {cfg['desc']}")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        out = pipe.step()
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    lb_evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        if proto is None:  # detect workloads: the dominant kernel is the letterbox
+            lb_evs[k][0].record()
+            pipe.ops.letterbox(pipe.frames, (pipe.S, pipe.S), pad_value=114, swap_rb=True, out=pipe.lb_out)
+            lb_evs[k][1].record()
+            det, count, anchor = pipe.ops.nms_v8(pipe.head, CONF, IOU, nc=cfg["nc"], max_det=MAX_DET)
+            fin = pipe.ops.finalize_detections(det, count, cfg["nc"], (pipe.S, pipe.S), (cfg["h"], cfg["w"]), MASK_CONF)
+            out = (det, count, anchor, fin, None)
+        else:
+            out = pipe.step(time_upsample=evs[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    det, count, anchor, fin, masks = out
+    n_surv = int(fin["keep_count"].sum().item())
+    stats = torch.tensor([cfg["batch"] * args.steps, n_surv, int(count.sum().item())], dtype=torch.int64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)   # per-shard counters gathered over RCCL for the report
+    elapsed = float(t.item())
+    total_images = int(stats[0].item())
+    value = total_images / elapsed
+
+    # ---- roofline of the dominant kernel (rank 0's own launches) -------------------------------
+    H0, W0, S, B = cfg["h"], cfg["w"], cfg["size"], cfg["batch"]
+    if proto is not None:
+        from object_detectors_amd.roofline import mask_upsample_bytes
+        kernel = "mask_upsample_kernel<uint8>"
+        ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        alg = mask_upsample_bytes(n_surv, H0, W0, S // 4, S // 4)
+    else:
+        from object_detectors_amd.roofline import letterbox_bytes
+        kernel = "letterbox_kernel<float,128>"
+        ms = float(np.mean([a.elapsed_time(b) for a, b in lb_evs]))
+        alg = B * letterbox_bytes(H0, W0, S, S, 4)
+    achieved = alg / (ms * 1e-3) / 1e9
+    roof = {"kernel": kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(ms, 4),
+            "algorithmic_bytes_per_launch": int(alg)}
+
+    res = None
+    if rank == 0:
+        cpu = None
+        if args.cpu_images > 0:
+            threads = min(16, os.cpu_count() or 1)
+            ips, dt, _ = cpu_baseline(cfg, frames, head, proto, min(args.cpu_images, B), threads)
+            cpu = {"value": round(ips, 3), "unit": "images/s", "cores": threads, "kind": "port",
+                   "sample": f"first {min(args.cpu_images, B)} images of the same workload through the numpy/torch-CPU oracle "
+                             f"(letterbox+NMS+scale/clip/threshold+process_mask), {dt:.1f}s"}
+        res = {
+            "metric": "pre+post images/sec per node, YOLOv8-seg 640 bs64; % HBM roofline",
+            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8->f32 (integer resize, fp32 NMS/masks)", "data": "synthetic",
+            "config": {"workload": cfg["desc"], "name": args.workload, "per_gpu_batch": B, "conf": CONF, "iou": IOU,
+                       "max_det": MAX_DET, "survivors_per_batch": n_surv, "nms_kept_per_batch": int(count.sum().item()),
+                       "mask_dtype": "uint8", "forward": "excluded", "sharding": f"{world} x independent batches, no collective on the hot path"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return res
+
+
+if __name__ == "__main__":
+    main()

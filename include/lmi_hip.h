@@ -172,11 +172,22 @@ int lmi_finalize_detections(float *det, const int32_t *count, int batch, int max
  *   out_masks  [device] survivors' masks written back to back in slot order; with uniform
  *              originals this is an array (capacity_masks, H0, W0) of out_dtype (LMI_U8|LMI_F32)
  *   capacity_masks  number of mask planes out_masks can hold; slots beyond it are skipped and
- *              counted in overflow[0] ([device] int32, may be NULL)
+ *              their number is written to overflow[0] ([device] int32, may be NULL)
  *   workspace  [device] >= lmi_mask_workspace_bytes(capacity_masks, mh, mw), 256-byte aligned
  * Only uniform originals (every image H0 x W0) are supported by this entry.
+ * lmi_process_mask = lmi_mask_logits (the MFMA GEMM into `workspace`) followed by
+ * lmi_mask_upsample (crop + bilinear + box crop + threshold from `workspace`); the two halves are
+ * exported so a caller can time or schedule them separately.
  */
 int64_t lmi_mask_workspace_bytes(int64_t capacity_masks, int mh, int mw);
+int lmi_mask_logits(const float *proto, int batch, int nm, int mh, int mw, const float *det,
+                    int max_det, int det_stride, const int32_t *slot_map, const int32_t *slot_base,
+                    int h0, int w0, int64_t capacity_masks, void *workspace,
+                    int64_t workspace_bytes, void *stream);
+int lmi_mask_upsample(const void *workspace, int batch, int nm, int mh, int mw, const float *det,
+                      int max_det, int det_stride, const int32_t *slot_map,
+                      const int32_t *slot_base, int h0, int w0, void *out_masks, int out_dtype,
+                      int64_t capacity_masks, int32_t *overflow, void *stream);
 int lmi_process_mask(const float *proto, int batch, int nm, int mh, int mw, const float *det,
                      int max_det, int det_stride, const int32_t *slot_map,
                      const int32_t *slot_base, int h0, int w0, void *out_masks, int out_dtype,

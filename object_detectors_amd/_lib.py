@@ -43,6 +43,10 @@ SIGNATURES = {
                                           C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lmi_mask_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
+    "lmi_mask_logits": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "lmi_mask_upsample": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "lmi_process_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p,
                                    C.c_void_p, C.c_int64, C.c_void_p]),

@@ -176,7 +176,10 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
   const int span_bytes = (sx_max - sx_min + 1) * 3;
   const int nchunk = (span_bytes + 15 + 15) >> 4;              // covers any 0..15 byte alignment shift
   {
-    const uint32_t frame_bytes = (uint32_t)((long long)(h - 1) * stride + 3LL * w);
+    // Range-checked loads are dropped whole when they cross num_records, so the range is the frame
+    // rounded up to the 16-byte chunk size.  The base is 16-byte aligned, hence the rounded end is too and
+    // the last chunk stays inside the page that holds the frame's last byte: no access can fault.
+    const uint32_t frame_bytes = (uint32_t)(((long long)(h - 1) * stride + 3LL * w + 15) & ~15LL);
     uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(reinterpret_cast<uintptr_t>(src) & 0xffffffffu));
     uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(reinterpret_cast<uintptr_t>(src) >> 32));
     const void *ubase = reinterpret_cast<const void *>(((uintptr_t)hi << 32) | lo);

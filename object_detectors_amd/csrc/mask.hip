@@ -150,11 +150,9 @@ __global__ __launch_bounds__(256) void mask_upsample_kernel(UpParams U) {
 
   const int total = U.slot_base[U.batch];
   const long long slot = blockIdx.y;
-  if (slot >= total) return;
-  if (slot >= U.capacity) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && U.overflow) atomicAdd(U.overflow, 1);
-    return;
-  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && U.overflow)
+    *U.overflow = total > U.capacity ? (int)(total - U.capacity) : 0;  // survivors that did not fit
+  if (slot >= total || slot >= U.capacity) return;
   const int e = U.slot_map[slot];
   const float *d = U.det + (size_t)e * U.det_stride;
   const float bx1 = d[0], by1 = d[1], bx2 = d[2], by2 = d[3];
@@ -246,45 +244,53 @@ int64_t lmi_mask_workspace_bytes(int64_t capacity_masks, int mh, int mw) {
   return (int64_t)align_up((size_t)capacity_masks * mh * mw * sizeof(float), 256);
 }
 
-int lmi_process_mask(const float *proto, int batch, int nm, int mh, int mw, const float *det, int max_det,
-                     int det_stride, const int32_t *slot_map, const int32_t *slot_base, int h0, int w0,
-                     void *out_masks, int out_dtype, int64_t capacity_masks, int32_t *overflow, void *workspace,
-                     int64_t workspace_bytes, void *stream) {
-  LMI_REQUIRE(proto && det && slot_map && slot_base && out_masks && workspace, LMI_ERR_BAD_ARG, "lmi_process_mask: NULL pointer");
-  LMI_REQUIRE(nm == LMI_MAX_MASK_DIM, LMI_ERR_LIMIT, "lmi_process_mask: nm=%d, only %d prototype channels are supported", nm, LMI_MAX_MASK_DIM);
+static int mask_check_common(const char *fn, int batch, int nm, int mh, int mw, int h0, int w0, int max_det, int det_stride,
+                             int64_t capacity_masks, MaskGeom &g) {
+  LMI_REQUIRE(nm == LMI_MAX_MASK_DIM, LMI_ERR_LIMIT, "%s: nm=%d, only %d prototype channels are supported", fn, nm, LMI_MAX_MASK_DIM);
   LMI_REQUIRE(batch > 0 && batch <= 65535 && mh > 0 && mw > 0 && h0 > 0 && w0 > 0 && max_det > 0 && det_stride >= 6 + nm, LMI_ERR_BAD_ARG,
-              "lmi_process_mask: bad shape batch=%d proto=%dx%d orig=%dx%d max_det=%d det_stride=%d", batch, mh, mw, h0, w0, max_det, det_stride);
-  LMI_REQUIRE(out_dtype == LMI_U8 || out_dtype == LMI_F32, LMI_ERR_BAD_ARG, "lmi_process_mask: out_dtype must be LMI_U8 or LMI_F32");
-  LMI_REQUIRE(capacity_masks > 0 && capacity_masks <= 65535, LMI_ERR_LIMIT, "lmi_process_mask: capacity_masks %lld not in 1..65535", (long long)capacity_masks);
-  LMI_REQUIRE(lmi_is_aligned(out_masks, 16) && lmi_is_aligned(workspace, 256) && lmi_is_aligned(proto, 4), LMI_ERR_ALIGNMENT,
-              "lmi_process_mask: out_masks must be 16-byte and workspace 256-byte aligned");
-  LMI_REQUIRE(workspace_bytes >= lmi_mask_workspace_bytes(capacity_masks, mh, mw), LMI_ERR_WORKSPACE, "lmi_process_mask: workspace %lld < %lld bytes",
-              (long long)workspace_bytes, (long long)lmi_mask_workspace_bytes(capacity_masks, mh, mw));
-  MaskGeom g;
+              "%s: bad shape batch=%d proto=%dx%d orig=%dx%d max_det=%d det_stride=%d", fn, batch, mh, mw, h0, w0, max_det, det_stride);
+  LMI_REQUIRE(capacity_masks > 0 && capacity_masks <= 65535, LMI_ERR_LIMIT, "%s: capacity_masks %lld not in 1..65535", fn, (long long)capacity_masks);
   crop_window(mh, mw, h0, w0, g);
   const int wh = g.bottom - g.top, ww = g.right - g.left;
-  LMI_REQUIRE(wh > 0 && ww > 0 && g.top >= 0 && g.left >= 0 && g.bottom <= mh && g.right <= mw, LMI_ERR_BAD_ARG, "lmi_process_mask: empty crop window");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  LMI_REQUIRE(wh > 0 && ww > 0 && g.top >= 0 && g.left >= 0 && g.bottom <= mh && g.right <= mw, LMI_ERR_BAD_ARG, "%s: empty crop window", fn);
+  return LMI_OK;
+}
 
-  if (overflow) {
-    hipError_t e = hipMemsetAsync(overflow, 0, sizeof(int32_t), s);
-    if (e != hipSuccess) { lmi_set_error("lmi_process_mask: hipMemsetAsync: %s", hipGetErrorString(e)); return LMI_ERR_LAUNCH; }
-  }
-
+int lmi_mask_logits(const float *proto, int batch, int nm, int mh, int mw, const float *det, int max_det, int det_stride,
+                    const int32_t *slot_map, const int32_t *slot_base, int h0, int w0, int64_t capacity_masks,
+                    void *workspace, int64_t workspace_bytes, void *stream) {
+  LMI_REQUIRE(proto && det && slot_map && slot_base && workspace, LMI_ERR_BAD_ARG, "lmi_mask_logits: NULL pointer");
+  MaskGeom g;
+  int rc = mask_check_common("lmi_mask_logits", batch, nm, mh, mw, h0, w0, max_det, det_stride, capacity_masks, g);
+  if (rc) return rc;
+  LMI_REQUIRE(lmi_is_aligned(workspace, 256) && lmi_is_aligned(proto, 4), LMI_ERR_ALIGNMENT, "lmi_mask_logits: workspace must be 256-byte aligned");
+  LMI_REQUIRE(workspace_bytes >= lmi_mask_workspace_bytes(capacity_masks, mh, mw), LMI_ERR_WORKSPACE, "lmi_mask_logits: workspace %lld < %lld bytes",
+              (long long)workspace_bytes, (long long)lmi_mask_workspace_bytes(capacity_masks, mh, mw));
   GemmParams G;
   G.proto = proto; G.det = det; G.slot_map = slot_map; G.slot_base = slot_base; G.logits = reinterpret_cast<float *>(workspace);
   G.batch = batch; G.max_det = max_det; G.det_stride = det_stride; G.capacity = capacity_masks; G.g = g;
-  const int npx = wh * mw;
+  const int npx = (g.bottom - g.top) * mw;
   const int ntiles = (npx + 31) / 32;
   G.tiles_per_block = 4;
   const int gx = (ntiles + 4 * G.tiles_per_block - 1) / (4 * G.tiles_per_block);
   dim3 ggrid(gx, (max_det + 31) / 32, batch);
-  hipLaunchKernelGGL(mask_gemm_kernel, ggrid, dim3(256), 0, s, G);
-  int rc = lmi_check_launch("mask_gemm_kernel");
-  if (rc) return rc;
+  hipLaunchKernelGGL(mask_gemm_kernel, ggrid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
+  return lmi_check_launch("mask_gemm_kernel");
+}
 
+int lmi_mask_upsample(const void *workspace, int batch, int nm, int mh, int mw, const float *det, int max_det, int det_stride,
+                      const int32_t *slot_map, const int32_t *slot_base, int h0, int w0, void *out_masks, int out_dtype,
+                      int64_t capacity_masks, int32_t *overflow, void *stream) {
+  LMI_REQUIRE(workspace && det && slot_map && slot_base && out_masks, LMI_ERR_BAD_ARG, "lmi_mask_upsample: NULL pointer");
+  MaskGeom g;
+  int rc = mask_check_common("lmi_mask_upsample", batch, nm, mh, mw, h0, w0, max_det, det_stride, capacity_masks, g);
+  if (rc) return rc;
+  LMI_REQUIRE(out_dtype == LMI_U8 || out_dtype == LMI_F32, LMI_ERR_BAD_ARG, "lmi_mask_upsample: out_dtype must be LMI_U8 or LMI_F32");
+  LMI_REQUIRE(lmi_is_aligned(out_masks, 16) && lmi_is_aligned(workspace, 256), LMI_ERR_ALIGNMENT,
+              "lmi_mask_upsample: out_masks must be 16-byte and workspace 256-byte aligned");
+  const int wh = g.bottom - g.top, ww = g.right - g.left;
   UpParams U;
-  U.det = det; U.slot_map = slot_map; U.slot_base = slot_base; U.logits = G.logits; U.out = out_masks;
+  U.det = det; U.slot_map = slot_map; U.slot_base = slot_base; U.logits = reinterpret_cast<const float *>(workspace); U.out = out_masks;
   U.batch = batch; U.max_det = max_det; U.det_stride = det_stride; U.capacity = capacity_masks; U.g = g; U.overflow = overflow;
   // rows per strip: as many as keep the staged logits rows within 48 KiB of LDS
   int rpb = 16;
@@ -294,15 +300,27 @@ int lmi_process_mask(const float *proto, int batch, int nm, int mh, int mw, cons
     if (lds_rows > wh) lds_rows = wh;
     if ((size_t)lds_rows * ww * sizeof(float) <= 48 * 1024 || rpb == 1) break;
   }
-  LMI_REQUIRE((size_t)lds_rows * ww * sizeof(float) <= 64 * 1024, LMI_ERR_LIMIT, "lmi_process_mask: prototype rows too wide for LDS (%d)", ww);
+  LMI_REQUIRE((size_t)lds_rows * ww * sizeof(float) <= 64 * 1024, LMI_ERR_LIMIT, "lmi_mask_upsample: prototype rows too wide for LDS (%d)", ww);
   U.rows_per_block = rpb; U.lds_rows = lds_rows;
   const size_t lds = (size_t)lds_rows * ww * sizeof(float);
   dim3 ugrid((h0 + rpb - 1) / rpb, (unsigned)capacity_masks);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (out_dtype == LMI_U8)
     hipLaunchKernelGGL(mask_upsample_kernel<uint8_t>, ugrid, dim3(256), lds, s, U);
   else
     hipLaunchKernelGGL(mask_upsample_kernel<float>, ugrid, dim3(256), lds, s, U);
   return lmi_check_launch("mask_upsample_kernel");
+}
+
+int lmi_process_mask(const float *proto, int batch, int nm, int mh, int mw, const float *det, int max_det,
+                     int det_stride, const int32_t *slot_map, const int32_t *slot_base, int h0, int w0,
+                     void *out_masks, int out_dtype, int64_t capacity_masks, int32_t *overflow, void *workspace,
+                     int64_t workspace_bytes, void *stream) {
+  int rc = lmi_mask_logits(proto, batch, nm, mh, mw, det, max_det, det_stride, slot_map, slot_base, h0, w0, capacity_masks,
+                           workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  return lmi_mask_upsample(workspace, batch, nm, mh, mw, det, max_det, det_stride, slot_map, slot_base, h0, w0, out_masks,
+                           out_dtype, capacity_masks, overflow, stream);
 }
 
 }  // extern "C"

@@ -197,10 +197,12 @@ def finalize_detections(det: torch.Tensor, count: torch.Tensor, nc: int, model_h
 
 def process_mask(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.Tensor, slot_base: torch.Tensor,
                  orig_hw: Tuple[int, int], capacity: int, out_dtype: torch.dtype = torch.uint8,
-                 out: Optional[torch.Tensor] = None):
+                 out: Optional[torch.Tensor] = None, split_events=None):
     """`process_mask_native` + `masks[M]` for the whole batch (uniform original size).
 
-    Returns (masks (capacity,H0,W0) of uint8|float32 in slot order, overflow (1,) int32)."""
+    Returns (masks (capacity,H0,W0) of uint8|float32 in slot order, overflow (1,) int32).
+    split_events: optional (start, end) torch.cuda.Event pair recorded around the upsample kernel
+    alone (the two halves are then enqueued through lmi_mask_logits / lmi_mask_upsample)."""
     _need_cuda(proto, "proto")
     if proto.dtype != torch.float32:
         proto = proto.float()
@@ -216,7 +218,15 @@ def process_mask(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.Tensor,
     overflow = torch.empty((1,), dtype=torch.int32, device=proto.device)
     nbytes = int(_L.lmi_mask_workspace_bytes(capacity, mh, mw))
     ws = _ws.get(proto.device, "mask", nbytes)
-    check(_L.lmi_process_mask(proto.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
-                              slot_base.data_ptr(), h0, w0, out.data_ptr(), ldt, capacity, overflow.data_ptr(),
-                              ws.data_ptr(), ws.numel(), _stream()))
+    if split_events is None:
+        check(_L.lmi_process_mask(proto.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
+                                  slot_base.data_ptr(), h0, w0, out.data_ptr(), ldt, capacity, overflow.data_ptr(),
+                                  ws.data_ptr(), ws.numel(), _stream()))
+    else:
+        check(_L.lmi_mask_logits(proto.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
+                                 slot_base.data_ptr(), h0, w0, capacity, ws.data_ptr(), ws.numel(), _stream()))
+        split_events[0].record()
+        check(_L.lmi_mask_upsample(ws.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
+                                   slot_base.data_ptr(), h0, w0, out.data_ptr(), ldt, capacity, overflow.data_ptr(), _stream()))
+        split_events[1].record()
     return out, overflow

@@ -49,7 +49,7 @@ def head(rng: np.random.Generator, batch: int, nc: int, nm: int, size: int, obje
             p[b, 3, a] = h * np.exp(rng.normal(0, 0.05, k))
             p[b, 4 + cls, a] = rng.uniform(0.3, 0.95) * rng.uniform(0.7, 1.0, k)
             if nm:  # clustered anchors share a mask
-                p[b, 4 + nc:, a] = rng.normal(0, 0.5, (nm, 1)).astype(F32) + rng.normal(0, 0.02, (nm, k)).astype(F32)
+                p[b, 4 + nc:, a] = (rng.normal(0, 0.5, (nm, 1)) + rng.normal(0, 0.02, (nm, k))).astype(F32).T
         # distinct best scores per image: nudge duplicates by one ulp steps
         best = p[b, 4:4 + nc].max(0)
         arg = p[b, 4:4 + nc].argmax(0)
