@@ -88,7 +88,7 @@ class Pipeline:
         return det, count, anchor, fin, masks
 
 
-def cpu_baseline(cfg, frames, head, proto, n_img, threads):
+def cpu_baseline(cfg, frames, head, proto, n_img, threads, max_seconds=20.0):
     """The oracle (CPU restatement of the reference path) on the first n_img images of the workload."""
     from oracle import boxes as OB, cv2_resize as OC, masks as OM, nms as ON
     torch.set_num_threads(threads)
@@ -98,7 +98,11 @@ def cpu_baseline(cfg, frames, head, proto, n_img, threads):
     S = cfg["size"]
     t0 = time.perf_counter()
     ndet = 0
+    done = 0
     for i in range(n_img):
+        if time.perf_counter() - t0 > max_seconds:
+            break
+        done += 1
         OC.letterbox_u8(f[i], S, S, pad_value=114, swap_rb=True)
         (det, _), = ON.non_max_suppression(p[i:i + 1], CONF, IOU, nc=cfg["nc"], max_det=MAX_DET)
         if len(det):
@@ -109,7 +113,7 @@ def cpu_baseline(cfg, frames, head, proto, n_img, threads):
                 m = m.astype(np.uint8)
             ndet += int(M.sum())
     dt = time.perf_counter() - t0
-    return n_img / dt, dt, ndet
+    return done / dt, dt, done
 
 
 def main():
@@ -118,7 +122,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="seg640", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-images", type=int, default=8, help="images of the workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-images", type=int, default=64, help="at most this many images of the workload are timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="stop the CPU sample after this much wall time")
     ap.add_argument("--seed", type=int, default=2)
     args = ap.parse_args()
 
@@ -200,9 +205,9 @@ def main():
         cpu = None
         if args.cpu_images > 0:
             threads = min(16, os.cpu_count() or 1)
-            ips, dt, _ = cpu_baseline(cfg, frames, head, proto, min(args.cpu_images, B), threads)
+            ips, dt, n_done = cpu_baseline(cfg, frames, head, proto, min(args.cpu_images, B), threads, args.cpu_seconds)
             cpu = {"value": round(ips, 3), "unit": "images/s", "cores": threads, "kind": "port",
-                   "sample": f"first {min(args.cpu_images, B)} images of the same workload through the numpy/torch-CPU oracle "
+                   "sample": f"first {n_done} images of the same workload through the numpy/torch-CPU oracle "
                              f"(letterbox+NMS+scale/clip/threshold+process_mask), {dt:.1f}s"}
         res = {
             "metric": "pre+post images/sec per node, YOLOv8-seg 640 bs64; % HBM roofline",

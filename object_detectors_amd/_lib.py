@@ -5,6 +5,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must come first: the library has to bind to the HIP runtime torch ships and uses
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblmi_hip.so")
 
