@@ -196,8 +196,16 @@ def main():
         ms = float(np.mean([a.elapsed_time(b) for a, b in lb_evs]))
         alg = B * letterbox_bytes(H0, W0, S, S, 4)
     achieved = alg / (ms * 1e-3) / 1e9
+    # HBM traffic per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    # collected separately, gfx950 corrections applied; see profiles/traffic_<workload>.json)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+    if os.path.isfile(tpath):
+        with open(tpath) as f:
+            tk = json.load(f).get("kernels", {})
+        traffic = tk.get(kernel.split("<")[0], {}).get("traffic")
     roof = {"kernel": kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(ms, 4),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_ms": round(ms, 4),
             "algorithmic_bytes_per_launch": int(alg)}
 
     res = None
