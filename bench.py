@@ -172,15 +172,16 @@ def main():
             out = pipe.step(time_upsample=evs[k])
     barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     det, count, anchor, fin, masks = out
     n_surv = int(fin["keep_count"].sum().item())
-    stats = torch.tensor([cfg["batch"] * args.steps, n_surv, int(count.sum().item())], dtype=torch.int64, device=device)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)   # per-shard counters gathered over RCCL for the report
-    elapsed = float(t.item())
-    total_images = int(stats[0].item())
+    n_kept = int(count.sum().item())
+    from object_detectors_amd import shard
+    chk = shard.checksum_indices(torch.cat([anchor[b, :int(c)] for b, c in enumerate(count.tolist())]))
+    # the only communication of the run: per-shard counters gathered over RCCL (backend nccl) for the report
+    reports = shard.gather_report({"elapsed": elapsed, "images": cfg["batch"] * args.steps, "survivors": n_surv, "kept": n_kept,
+                                   "chk_hi": chk >> 31, "chk_lo": chk & (2 ** 31 - 1)}, device=device)
+    elapsed = max(r["elapsed"] for r in reports)
+    total_images = int(sum(r["images"] for r in reports))
     value = total_images / elapsed
 
     # ---- roofline of the dominant kernel (rank 0's own launches) -------------------------------
@@ -223,7 +224,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8->f32 (integer resize, fp32 NMS/masks)", "data": "synthetic",
             "config": {"workload": cfg["desc"], "name": args.workload, "per_gpu_batch": B, "conf": CONF, "iou": IOU,
-                       "max_det": MAX_DET, "survivors_per_batch": n_surv, "nms_kept_per_batch": int(count.sum().item()),
+                       "max_det": MAX_DET, "survivors_per_batch": n_surv, "nms_kept_per_batch": n_kept,
+                       "per_rank": [{"images": int(r["images"]), "survivors": int(r["survivors"]), "kept_checksum": (int(r["chk_hi"]) << 31) | int(r["chk_lo"])} for r in reports],
                        "mask_dtype": "uint8", "forward": "excluded", "sharding": f"{world} x independent batches, no collective on the hot path"},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -1,0 +1,346 @@
+"""Host side of the `Yolov8` wrapper: same methods, arguments, result dict and exceptions as the
+reference class (object_detectors/yolov8_lmi/model.py:42-324; twin
+object_detectors/ultralytics_lmi/yolo/model.py:42-324), with the arithmetic done by the HIP kernels
+behind `hip_ops` instead of torch / ultralytics / cv2 calls.
+
+What maps to what (reference line -> here):
+  preprocess   :112-134  -> lmi_preprocess_u8 (uint8 input) ; other dtypes keep the torch op sequence
+  postprocess  :178-252  -> lmi_nms_v8 + lmi_finalize_detections [+ lmi_process_mask], ONE device->host
+                            copy of counts/rows per batch instead of one `.item()` per detection
+  predict      :256-324  -> unchanged control flow (single image, operator-list revert)
+Additive (not in the reference): `letterbox()` / `predict_batch()` for batches of raw frames.
+
+There is no CPU fallback: with `device='cpu'` (or no GPU) construction still succeeds, like the
+reference, but preprocess/postprocess raise.
+"""
+from __future__ import annotations
+
+import collections
+import logging
+import os
+import time
+from typing import Union
+
+import numpy as np
+import torch
+
+from .segments import masks2segments
+
+
+def _hip_ops():
+    from . import hip_ops  # raises ImportError when liblmi_hip.so is missing -- deliberately loud
+    return hip_ops
+
+
+def load_backend(weights: str, device: torch.device, data=None, fp16=False):
+    """`AutoBackend(weights, device, data=data, fp16=fp16)` (model.py:68) when ultralytics is
+    installed; otherwise this package's own PyTorch YOLOv8 checkpoint (nets/yolov8.py)."""
+    try:
+        from ultralytics.nn.autobackend import AutoBackend  # type: ignore
+    except ImportError:
+        from .nets.yolov8 import load_checkpoint
+        return load_checkpoint(weights, device, fp16)
+    return AutoBackend(weights, device, data=data, fp16=fp16)
+
+
+def to_numpy(data):
+    """Tensor | list | ndarray -> ndarray (model.py:21-38)."""
+    if isinstance(data, torch.Tensor):
+        return data.cpu().numpy()
+    if isinstance(data, list):
+        return np.array(data)
+    if isinstance(data, np.ndarray):
+        return data
+    raise TypeError(f'Data type {type(data)} not supported')
+
+
+class Yolov8Core:
+    """Implementation shared by the v0 (`Yolov8`) and v1 (`Yolo`) registered classes."""
+
+    logger = logging.getLogger(__name__)
+    mask_dtype = torch.float32   # the reference returns 0./1. fp32 masks; torch.uint8 writes 4x fewer bytes
+
+    def _init(self, weights: str, device='gpu', data=None, fp16=False):
+        if not os.path.isfile(weights):
+            raise FileNotFoundError(f'File not found: {weights}')
+        self.device = torch.device('cpu')
+        if device == 'gpu':
+            if torch.cuda.is_available():
+                self.device = torch.device('cuda:0')
+            else:
+                self.logger.warning('GPU not available, using CPU')
+        self.model = load_backend(weights, self.device, data=data, fp16=fp16)
+        self.model.eval()
+        self.names = self.model.names
+        self._thres_cache = {}
+
+    # ---- forward / helpers (model.py:75-108) -----------------------------------------------------
+    @torch.inference_mode()
+    def forward(self, im):
+        return self.model(im)
+
+    @torch.inference_mode()
+    def from_numpy(self, x):
+        return torch.tensor(x).to(self.device) if isinstance(x, np.ndarray) else x
+
+    @torch.inference_mode()
+    def warmup(self, imgsz=[640, 640]):
+        if isinstance(imgsz, tuple):
+            imgsz = list(imgsz)
+        im = torch.empty(*([1, 3] + imgsz), dtype=torch.half if self.model.fp16 else torch.float, device=self.device)
+        self.forward(im)
+
+    def _require_gpu(self, what):
+        if self.device.type != 'cuda':
+            raise RuntimeError(f'{what}: this build runs its pre/post-processing in HIP kernels and has no CPU fallback '
+                               f'(device is {self.device})')
+
+    # ---- preprocess (model.py:112-134) -----------------------------------------------------------
+    @torch.inference_mode()
+    def preprocess(self, im):
+        self._require_gpu('preprocess')
+        if isinstance(im, np.ndarray):
+            im = self.from_numpy(im)
+        im = im.to(self.device)
+        if im.dtype == torch.uint8 and im.ndim in (2, 3) and (im.ndim == 2 or im.shape[-1] in (1, 3)):
+            return _hip_ops().preprocess_u8(im, fp16=bool(self.model.fp16))
+        # non-uint8 inputs: the reference's op sequence verbatim (cast precedes the division)
+        if im.ndim == 2:
+            im = im.unsqueeze(-1)
+        if im.shape[-1] == 1:
+            im = im.expand(-1, -1, 3)
+        img = im.unsqueeze(0).permute((0, 3, 1, 2)).contiguous()
+        img = img.half() if self.model.fp16 else img.float()
+        img /= 255
+        return img
+
+    def load_with_preprocess(self, im_path: str):
+        """(preprocessed tensor, original RGB image) from .npy or an image file (model.py:137-153)."""
+        ext = os.path.splitext(im_path)[-1]
+        if ext == '.npy':
+            im0 = np.load(im_path)
+        else:
+            from PIL import Image
+            im0 = np.asarray(Image.open(im_path).convert('RGB'))
+        return self.preprocess(im0.copy()), im0
+
+    # ---- additive: batched letterbox -----------------------------------------------------------
+    @torch.inference_mode()
+    def letterbox(self, frames, imgsz=(640, 640), pad_value=114, swap_rb=False, stretch=False):
+        """Batch of raw uint8 HWC frames (list of arrays/tensors or a (B,H,W,3) tensor) ->
+        ((B,3,h,w) network input, operators per frame).  One fused kernel: cv2-INTER_LINEAR resize,
+        centred pad, optional BGR<->RGB, /255, NCHW."""
+        self._require_gpu('letterbox')
+        if isinstance(frames, np.ndarray):
+            frames = torch.from_numpy(frames)
+        if isinstance(frames, torch.Tensor):
+            frames = frames.to(self.device)
+        else:
+            frames = [(torch.from_numpy(f) if isinstance(f, np.ndarray) else f).to(self.device) for f in frames]
+        return _hip_ops().letterbox(frames, imgsz, pad_value=pad_value, swap_rb=swap_rb, fp16=bool(self.model.fp16), stretch=stretch)
+
+    # ---- thresholds (model.py:156-174, :223-232) ---------------------------------------------------
+    def get_min_conf(self, conf: Union[float, dict]):
+        if isinstance(conf, float):
+            return conf
+        if isinstance(conf, dict):
+            conf2 = 1
+            class_names = set(self.model.names.values())
+            for k, v in conf.items():
+                if k in class_names:
+                    conf2 = min(conf2, v)
+            if conf2 == 1:
+                self.logger.warning('No class matches in confidence dict, set to 1.0 for all classes.')
+            return conf2
+        raise TypeError(f'Confidence type {type(conf)} not supported')
+
+    def _class_thresholds(self, conf):
+        """float -> itself; dict -> float64 device tensor (nc,) with `conf.get(name, 1)` per class id."""
+        if isinstance(conf, float):
+            return conf
+        nc = len(self.model.names)
+        key = tuple(sorted(conf.items()))
+        t = self._thres_cache.get(key)
+        if t is None:
+            t = torch.tensor([conf.get(self.model.names[i], 1) for i in range(nc)], dtype=torch.float64, device=self.device)
+            self._thres_cache = {key: t}
+        return t
+
+    # ---- postprocess (model.py:178-252) ----------------------------------------------------------
+    @torch.inference_mode()
+    def postprocess(self, preds, img, orig_imgs, conf: Union[float, dict], iou=0.45, agnostic=False, max_det=300, return_segments=True):
+        if isinstance(preds, (list, tuple)):
+            predict_mask = preds[0].shape[1] != 4 + len(self.model.names)
+        elif isinstance(preds, torch.Tensor):
+            predict_mask = False
+        else:
+            raise TypeError(f'Prediction type {type(preds)} not supported')
+        proto = None
+        if predict_mask:
+            proto = preds[1][-1] if len(preds[1]) == 3 else preds[1]
+            preds = preds[0]
+        elif isinstance(preds, (list, tuple)):
+            preds = preds[0]
+        self._require_gpu('postprocess')
+        ops = _hip_ops()
+        nc = len(self.model.names)
+        conf2 = self.get_min_conf(conf)
+        thres = self._class_thresholds(conf)
+        preds = preds.to(self.device)
+        B = preds.shape[0]
+        model_hw = tuple(img.shape[2:])
+
+        def orig_of(i):
+            return orig_imgs[i] if isinstance(orig_imgs, list) else orig_imgs
+        shapes = [tuple(orig_of(i).shape[:2]) for i in range(B)]
+        uniform = all(s == shapes[0] for s in shapes)
+
+        det, count, _ = ops.nms_v8(preds, float(conf2), float(iou), agnostic=bool(agnostic), max_det=int(max_det), nc=nc)
+        masks_by_image = [None] * B
+        if uniform:
+            fin = ops.finalize_detections(det, count, nc, model_hw, shapes[0], thres)
+            if predict_mask:
+                slot_base = fin["slot_base"].cpu().numpy()            # the one sync that sizes the mask buffer
+                total = int(slot_base[-1])
+                if total:
+                    masks, _ = ops.process_mask(proto.to(self.device), det, fin["slot_map"], fin["slot_base"], shapes[0], total, self.mask_dtype)
+                    masks_by_image = [masks[slot_base[i]:slot_base[i + 1]] for i in range(B)]
+            keep = fin["keep"]
+        else:
+            ohw = torch.tensor(shapes, dtype=torch.int32, device=self.device)
+            fin = ops.finalize_detections(det, count, nc, model_hw, ohw, thres, with_slots=False)
+            keep = fin["keep"]
+            if predict_mask:
+                for i in range(B):   # ragged originals: one mask launch per image
+                    masks_by_image[i] = self._masks_one_image(ops, proto[i:i + 1].to(self.device), det[i:i + 1], keep[i:i + 1], shapes[i])
+
+        count_h = count.cpu().numpy()
+        keep_h = keep.cpu().numpy().astype(bool)
+        det_h = det[:, :, :6].cpu().numpy()
+        return self._assemble(det, det_h, count_h, keep_h, masks_by_image, orig_imgs, predict_mask, return_segments)
+
+    def _masks_one_image(self, ops, proto1, det1, keep1, shape):
+        k = keep1[0].to(torch.int32)
+        m = int(k.sum().item())
+        if m == 0:
+            return torch.zeros((0,) + tuple(shape), dtype=self.mask_dtype, device=self.device)
+        idx = torch.nonzero(k, as_tuple=False).flatten().to(torch.int32)
+        slot_map = torch.zeros((det1.shape[1],), dtype=torch.int32, device=self.device)
+        slot_map[:m] = idx
+        slot_base = torch.tensor([0, m], dtype=torch.int32, device=self.device)
+        masks, _ = ops.process_mask(proto1, det1, slot_map, slot_base, shape, m, self.mask_dtype)
+        return masks
+
+    def _assemble(self, det, det_h, count_h, keep_h, masks_by_image, orig_imgs, predict_mask, return_segments):
+        """Result dict exactly as model.py:214-252 builds it (images with no NMS survivor add no entry)."""
+        results = collections.defaultdict(list)
+        names = self.model.names
+        for i in range(len(count_h)):
+            orig_img = orig_imgs[i] if isinstance(orig_imgs, list) else orig_imgs
+            return_tensor = isinstance(orig_img, torch.Tensor)
+            n = int(count_h[i])
+            if n == 0:
+                continue
+            M = keep_h[i, :n]
+            classes = np.array([names[int(c)] for c in det_h[i, :n, 5]])
+            if predict_mask:
+                masks = masks_by_image[i]
+                if masks is None:
+                    masks = torch.zeros((0,) + tuple(orig_img.shape[:2]), dtype=self.mask_dtype, device=self.device)
+                results['masks'].append(masks if return_tensor else masks.cpu().numpy())
+                if return_segments:
+                    segments = masks2segments(masks)
+                    if return_tensor:
+                        segments = [self.from_numpy(x) for x in segments]
+                    results['segments'].append(segments)
+            if return_tensor:
+                sel = torch.from_numpy(np.nonzero(M)[0]).to(det.device)
+                results['boxes'].append(det[i, :n, :4][sel])
+                results['scores'].append(det[i, :n, 4][sel])
+            else:
+                results['boxes'].append(det_h[i, :n, :4][M])
+                results['scores'].append(det_h[i, :n, 4][M])
+            results['classes'].append(classes[M].tolist())
+        return results
+
+    # ---- predict (model.py:256-324) --------------------------------------------------------------
+    @torch.inference_mode()
+    def predict(self, image, configs, operators=[], iou=0.4, agnostic=False, max_det=300, return_segments=True):
+        import gadget_utils.pipeline_utils as pipeline_utils
+        time_info = {}
+        t0 = time.time()
+        im = self.preprocess(image)
+        time_info['preproc'] = time.time() - t0
+        t0 = time.time()
+        pred = self.forward(im)
+        time_info['proc'] = time.time() - t0
+        t0 = time.time()
+        results = self.postprocess(pred, im, image, configs, iou, agnostic, max_det, return_segments)
+        results_dict = collections.defaultdict(list)
+        if not len(results['boxes']):
+            time_info['postproc'] = time.time() - t0
+            return results_dict, time_info
+        boxes, scores, classes = results['boxes'][0], results['scores'][0], results['classes'][0]
+        if len(results['masks']):
+            results_dict['masks'] = pipeline_utils.revert_masks_to_origin(results['masks'][0], operators)
+        if return_segments and len(results['segments']):
+            results_dict['segments'] = [pipeline_utils.revert_to_origin(seg, operators) for seg in results['segments'][0]]
+        results_dict['boxes'] = pipeline_utils.revert_to_origin(boxes, operators)
+        results_dict['scores'] = scores
+        results_dict['classes'] = classes
+        time_info['postproc'] = time.time() - t0
+        return results_dict, time_info
+
+    # ---- additive: batched predict on raw frames -------------------------------------------------
+    @torch.inference_mode()
+    def predict_batch(self, frames, configs, imgsz=(640, 640), swap_rb=False, iou=0.4, agnostic=False, max_det=300, return_segments=False):
+        """letterbox -> forward -> postprocess for a batch of raw frames; boxes and masks come back
+        in each frame's own pixel space (scale_boxes / process_mask undo the letterbox), so no
+        operator list is needed.  Returns (results dict as `postprocess`, time_info)."""
+        time_info = {}
+        t0 = time.time()
+        if isinstance(frames, (np.ndarray, torch.Tensor)) and frames.ndim == 3:
+            frames = [frames]
+        im, _ = self.letterbox(frames, imgsz, swap_rb=swap_rb)
+        time_info['preproc'] = time.time() - t0
+        t0 = time.time()
+        pred = self.forward(im)
+        time_info['proc'] = time.time() - t0
+        t0 = time.time()
+        origs = list(frames) if not isinstance(frames, list) else frames
+        results = self.postprocess(pred, im, origs, configs, iou, agnostic, max_det, return_segments)
+        time_info['postproc'] = time.time() - t0
+        return results, time_info
+
+    @staticmethod
+    @torch.inference_mode()
+    def annotate_image(results, image, colormap=None, line_thickness=None, hide_label=False, hide_bbox=False):
+        """Draw boxes (and blend masks) on a copy of the image (model.py:327-388).  Visualisation is
+        outside the accelerated path: plain numpy, no text labels (cv2 is not a dependency here)."""
+        boxes, classes, masks = results['boxes'], results['classes'], results['masks']
+        image = to_numpy(image).copy()
+        if not len(boxes):
+            return image
+        boxes = to_numpy(boxes)
+        if len(masks):
+            masks = to_numpy(masks)
+        if image.ndim == 2:
+            image = np.stack([image] * 3, -1)
+        h, w = image.shape[:2]
+        t = line_thickness or max(1, round(0.002 * (h + w) / 2))
+        rng = np.random.default_rng(0)
+        for i in range(len(boxes)):
+            color = np.array(colormap[classes[i]] if colormap is not None else rng.integers(0, 255, 3), dtype=np.float32)
+            if np.shape(boxes[i]) != (4,):
+                continue
+            if len(masks):
+                m = masks[i].astype(bool)
+                image[m] = (0.5 * image[m] + 0.5 * color).astype(image.dtype)
+            if not hide_bbox:
+                x1, y1, x2, y2 = (int(v) for v in boxes[i])
+                x1, y1, x2, y2 = max(x1, 0), max(y1, 0), min(x2, w - 1), min(y2, h - 1)
+                image[y1:y1 + t, x1:x2 + 1] = color
+                image[max(y2 - t + 1, 0):y2 + 1, x1:x2 + 1] = color
+                image[y1:y2 + 1, x1:x1 + t] = color
+                image[y1:y2 + 1, max(x2 - t + 1, 0):x2 + 1] = color
+        return image

@@ -1,0 +1,156 @@
+"""Host logic of the drop-in boundary, on CPU: top-level module names, registry semantics
+(object_detectors/object_detector.py:7-46), wrapper construction / thresholds / result-dict
+assembly (object_detectors/yolov8_lmi/model.py:46-72, :156-174, :214-252), the product
+pipeline_utils against the reference-generated fixtures, and contour tracing."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(ROOT, "object_detectors_amd", "dropin")
+if DROPIN not in sys.path:
+    sys.path.insert(0, DROPIN)
+
+import gadget_utils.pipeline_utils as pipeline_utils  # noqa: E402
+from object_detector import ObjectDetector  # noqa: E402
+from od_base import ODBase  # noqa: E402
+import od_models  # noqa: E402,F401
+from yolov8_lmi.model import Yolov8  # noqa: E402
+from ultralytics_lmi.yolo.model import Yolo  # noqa: E402
+from object_detectors_amd.nets.yolov8 import save_checkpoint  # noqa: E402
+from object_detectors_amd import segments as SG  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def weights(tmp_path_factory):
+    d = tmp_path_factory.mktemp("w")
+    det, seg = str(d / "y8n.pt"), str(d / "y8n-seg.pt")
+    names = {i: f"c{i}" for i in range(6)}
+    save_checkpoint(det, "n", 6, False, names)
+    save_checkpoint(seg, "n", 6, True, names)
+    return det, seg
+
+
+def test_registry_semantics(weights):
+    keys = set(ObjectDetector._registry)
+    for v, names in (("v0", ["yolov8"]), ("v1", ["yolov8", "yolov11"])):
+        for n in names:
+            for t in ("od", "seg"):
+                assert ("ultralytics", n, t, v, "{}") in keys
+    m = ObjectDetector(metadata=dict(version='v0', model_name='yolov8', task='od', framework='ultralytics'), weights=weights[0], device='cpu')
+    assert isinstance(m, Yolov8) and isinstance(m, ODBase) and not isinstance(m, ObjectDetector)
+    m1 = ObjectDetector(metadata=dict(version='v1', model_name='yolov11', task='seg', framework='ultralytics'), model_path=weights[1], device='cpu')
+    assert isinstance(m1, Yolo)
+    with pytest.raises(ValueError):
+        ObjectDetector(metadata=dict(version='v0', model_name='yolov8', task='od'), weights=weights[0])
+    with pytest.raises(ValueError):
+        ObjectDetector(metadata=dict(version='v9', model_name='yolov8', task='od', framework='ultralytics'), weights=weights[0])
+    with pytest.raises(ValueError):
+        ObjectDetector.register(metadata=dict(versions=['v0'], model_names=['yolov8'], tasks=['od'], frameworks=['ultralytics']))(Yolov8)
+    with pytest.raises(TypeError):
+        ODBase()
+
+
+def test_wrapper_construction_thresholds_and_cpu_refusal(weights):
+    with pytest.raises(FileNotFoundError):
+        Yolov8("/nonexistent/weights.pt")
+    m = Yolov8(weights[0], device='cpu')
+    assert m.device.type == 'cpu' and m.names[3] == "c3"
+    assert m.get_min_conf(0.5) == 0.5
+    assert m.get_min_conf({"c1": 0.3, "c2": 0.6, "zzz": 0.01}) == 0.3
+    assert m.get_min_conf({"zzz": 0.01}) == 1
+    with pytest.raises(TypeError):
+        m.get_min_conf(1)
+    t = m._class_thresholds({"c1": 0.3, "c2": 0.6})
+    assert t.dtype == torch.float64 and t.tolist() == [1, 0.3, 0.6, 1, 1, 1]
+    m.warmup([64, 64])
+    y = m.forward(torch.zeros(1, 3, 64, 64))
+    assert y.shape == (1, 10, 84)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.preprocess(np.zeros((64, 64, 3), np.uint8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.postprocess(y, torch.zeros(1, 3, 64, 64), np.zeros((64, 64, 3), np.uint8), 0.5)
+    with pytest.raises(TypeError):
+        m.postprocess("bad", None, None, 0.5)
+
+
+def test_result_dict_assembly_matches_reference_layout(weights):
+    m = Yolov8(weights[0], device='cpu')
+    det_h = np.zeros((3, 5, 6), np.float32)
+    det_h[0, :3] = [[1, 2, 3, 4, 0.9, 0], [5, 6, 7, 8, 0.6, 2], [9, 10, 11, 12, 0.4, 5]]
+    det_h[2, :1] = [[1, 1, 2, 2, 0.7, 1]]
+    count_h = np.array([3, 0, 1])
+    keep_h = np.zeros((3, 5), bool)
+    keep_h[0, [0, 2]] = True            # the middle detection failed its per-class threshold
+    origs = [np.zeros((8, 8, 3), np.uint8)] * 3
+    r = m._assemble(torch.from_numpy(det_h), det_h, count_h, keep_h, [None] * 3, origs, False, False)
+    # image 1 had no NMS survivor: it contributes NO entry (model.py:219-220); image 2 has one row, filtered out
+    assert len(r['boxes']) == 2 and set(r) == {'boxes', 'scores', 'classes'}
+    assert isinstance(r['boxes'][0], np.ndarray) and r['boxes'][0].tolist() == [[1, 2, 3, 4], [9, 10, 11, 12]]
+    assert r['classes'][0] == ['c0', 'c5'] and r['scores'][0].tolist() == [np.float32(0.9), np.float32(0.4)]
+    assert r['boxes'][1].shape == (0, 4) and r['classes'][1] == []
+    rt = m._assemble(torch.from_numpy(det_h), det_h, count_h, keep_h, [None] * 3, [torch.zeros(8, 8, 3)] * 3, False, False)
+    assert isinstance(rt['boxes'][0], torch.Tensor) and isinstance(rt['classes'][0], list)
+
+
+def test_pipeline_utils_matches_reference_fixtures(golden_dir):
+    gold = json.load(open(os.path.join(golden_dir, "l1_geometry.json")))
+    conv = lambda p, k: p if k == "list" else np.array(p, dtype={"f64": np.float64, "f32": np.float32}[k])
+    for rec in gold["revert"]:
+        x = conv(rec["pts"], rec["kind"])
+        if rec["tensor"]:
+            x = torch.as_tensor(x)
+        got = pipeline_utils.revert_to_origin(x, rec["ops"])
+        assert type(got) is (torch.Tensor if rec["tensor"] else (list if rec["kind"] == "list" else np.ndarray))
+        assert np.array_equal(np.asarray(got.tolist() if hasattr(got, "tolist") else got, dtype=np.float64), np.asarray(rec["out"], dtype=np.float64))
+    for rec in gold["apply"]:
+        got = pipeline_utils.apply_operations(conv(rec["pts"], rec["kind"]), rec["ops"])
+        assert np.array_equal(np.asarray(got, dtype=np.float64), np.asarray(rec["out"], dtype=np.float64))
+
+    def pattern(h, w, c=3):
+        y, x, ch = np.meshgrid(np.arange(h), np.arange(w), np.arange(c), indexing="ij")
+        return ((37 * y + 11 * x + 101 * ch) % 256).astype(np.uint8)
+    for rec in gold["fit"]:
+        im = pattern(rec["h"], rec["w"])
+        for fn in (pipeline_utils.fit_im_to_size, pipeline_utils.fit_array_to_size):
+            out, *pads = fn(im, W=rec["W"], H=rec["H"])
+            assert pads == rec["pads"] and list(out.shape) == rec["shape"] and int(out.astype(np.int64).sum()) == rec["sum"]
+        t, *pads = pipeline_utils.fit_im_to_size(torch.from_numpy(im), W=rec["W"], H=rec["H"])
+        assert isinstance(t, torch.Tensor) and pads == rec["pads"]
+    torch.set_num_threads(1)   # the fixtures were generated single-threaded (aten's CPU bilinear is thread-count dependent)
+    for rec in gold["resize"]:
+        out = pipeline_utils.resize_image(pattern(rec["h"], rec["w"]), **rec["kw"])
+        assert list(out.shape) == rec["shape"] and str(out.dtype) == rec["dtype"]
+        if "out" in rec:
+            assert np.array_equal(out, np.array(rec["out"], dtype=np.uint8))
+    for rec in gold["mask_revert"]:
+        shape = rec["shape"]
+        mk = pattern(*shape) if len(shape) == 3 else pattern(shape[0], shape[1], 1)[:, :, 0]
+        out = pipeline_utils.revert_mask_to_origin(mk, rec["ops"])
+        assert list(out.shape) == rec["out_shape"] and int(np.asarray(out).astype(np.int64).sum()) == rec["sum"]
+    with pytest.raises(Exception):
+        pipeline_utils.revert_to_origin(np.zeros((2, 3)), [])
+
+
+def test_external_contours():
+    m = np.zeros((12, 14), np.uint8)
+    m[2:7, 3:9] = 1                     # rectangle 5x6 with a hole and a nested blob (not external)
+    m[3:6, 4:8] = 0
+    m[4, 5] = 1
+    m[9, 11] = 1                        # isolated pixel
+    cs = SG.find_external_contours(m)
+    assert len(cs) == 2
+    rect = {tuple(p) for p in cs[0].tolist()}
+    assert rect == {(3, 2), (3, 6), (8, 6), (8, 2)}      # collinear runs collapsed to the corners
+    assert cs[1].tolist() == [[11, 9]]
+    segs = SG.masks2segments(np.stack([m, np.zeros_like(m)]))
+    assert segs[0].shape == (5, 2) and segs[0].dtype == np.float32 and segs[1].shape == (0, 2)
+    assert SG.masks2segments(np.stack([m]), strategy="largest")[0].shape == (4, 2)
+    # a diagonal line: 8-connected, traced out and back
+    d = np.eye(5, dtype=np.uint8)
+    (c,) = SG.find_external_contours(d)
+    assert c[0].tolist() == [0, 0] and [4, 4] in c.tolist()
