@@ -1,0 +1,128 @@
+"""End-to-end drop-in test on the GPU, modelled on the reference's own wrapper tests
+(tests/object_detectors/yolov8_lmi/test_yolov8_model.py:72-126,169-178): build the wrapper
+directly and through ObjectDetector, run predict on a resized frame with an operator list, check
+the result dict -- but here every field is also compared with the CPU oracle fed the same head
+output, which the reference's smoke-level assertions never do."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(ROOT, "object_detectors_amd", "dropin")
+if DROPIN not in sys.path:
+    sys.path.insert(0, DROPIN)
+
+from oracle import boxes as OB, geometry as OG, masks as OM, nms as ON, preprocess as OP  # noqa: E402
+from object_detectors_amd import synth  # noqa: E402
+from object_detectors_amd.nets.yolov8 import YoloV8  # noqa: E402
+
+NAMES = {0: "person", 1: "car", 2: "dog", 3: "cat"}
+
+
+@pytest.fixture(scope="module")
+def models(tmp_path_factory):
+    from object_detector import ObjectDetector
+    import od_models  # noqa: F401
+    from yolov8_lmi.model import Yolov8
+    d = tmp_path_factory.mktemp("w")
+    out = {}
+    for seg in (False, True):
+        torch.manual_seed(7)
+        m = YoloV8("n", 4, seg, NAMES)
+        for conv in m.head.cv3:                      # spread the class scores so that NMS has work to do
+            conv[-1].bias.data.normal_(-2.0, 0.5)
+            conv[-1].weight.data.mul_(8.0)
+        path = str(d / ("seg.pt" if seg else "det.pt"))
+        torch.save({"format": "lmi-yolov8-torch", "scale": "n", "nc": 4, "seg": seg, "names": NAMES, "state_dict": m.state_dict()}, path)
+        out[seg] = path
+    det = Yolov8(out[False])
+    seg = ObjectDetector(metadata=dict(version='v0', model_name='yolov8', task='seg', framework='ultralytics'), weights=out[True])
+    assert det.device.type == "cuda" and isinstance(seg, Yolov8)
+    return det, seg
+
+
+def oracle_postprocess(pred, proto, model_hw, orig_hw, conf, names, iou, agnostic=False, max_det=300):
+    nc = len(names)
+    conf2 = OB.min_conf(conf, names)
+    (rd, ra), = ON.non_max_suppression(pred, conf2, iou, agnostic=agnostic, max_det=max_det, nc=nc)
+    boxes = OB.scale_boxes(model_hw, rd[:, :4], orig_hw + (3,))
+    M = OB.class_filter(rd[:, 4], rd[:, 5], OB.class_thresholds(conf, names, nc))
+    masks = OM.process_mask_native(proto, rd[:, 6:], boxes, orig_hw)[M] if proto is not None else None
+    return boxes[M], rd[M, 4], [names[int(c)] for c in rd[M, 5]], masks
+
+
+@pytest.mark.parametrize("conf", [0.3, {"person": 0.2, "car": 0.25, "dog": 0.3, "cat": 0.35, "unknown": 0.01}, {"cat": 0.2}])
+def test_predict_det_numpy_and_tensor(models, conf):
+    det, _ = models
+    rng = np.random.default_rng(0)
+    frame = synth.frames_u8(rng, 1, 240, 320)[0]
+    # the reference's callers hand predict() a frame already at model size plus the operator list that
+    # produced it (test_yolov8_model.py:84-88); here: a 448x640 original "resized" to 224x320
+    resized = np.ascontiguousarray(frame[:224, :320])
+    ops = [{'resize': (320, 224, 640, 448)}]
+    det.warmup([224, 320])
+    out, tinfo = det.predict(resized, conf, operators=ops, iou=0.4)
+    assert set(tinfo) == {'preproc', 'proc', 'postproc'}
+    # oracle on the same head output
+    im = det.preprocess(resized)
+    assert np.array_equal(im.cpu().numpy(), OP.preprocess(resized))
+    pred = det.forward(im).cpu().numpy()
+    boxes, scores, classes, _ = oracle_postprocess(pred, None, (224, 320), (224, 320), conf, NAMES, 0.4)
+    assert len(boxes) > 0
+    assert isinstance(out['boxes'], np.ndarray) and isinstance(out['classes'], list)
+    assert np.array_equal(out['boxes'], OG.revert_to_origin(boxes, ops))
+    assert np.array_equal(out['scores'], scores) and out['classes'] == classes
+    # tensor in -> tensors out, on the GPU (test_yolov8_model.py:122-126)
+    out_t, _ = det.predict(torch.from_numpy(resized).cuda(), conf, operators=ops, iou=0.4)
+    assert out_t['boxes'].is_cuda and out_t['scores'].is_cuda
+    assert np.array_equal(out_t['boxes'].cpu().numpy(), out['boxes'])
+    img = det.annotate_image(out, resized)
+    assert img.shape == resized.shape
+
+
+def _conf_for(pred):
+    """a threshold inside the score range of whatever the random-init head happens to output (many
+    anchors share a score there, which also exercises the tie order)"""
+    best = pred[:, 4:8].max(1)
+    return float((best.min() + 3 * best.max()) / 4)
+
+
+def test_predict_seg_masks_and_segments(models):
+    _, seg = models
+    rng = np.random.default_rng(1)
+    frame = synth.frames_u8(rng, 1, 256, 256)[0]
+    im = seg.preprocess(frame)
+    y = seg.forward(im)
+    pred, proto = y[0].cpu().numpy(), y[1][-1][0].cpu().numpy()
+    conf = _conf_for(pred)
+    out, _ = seg.predict(frame, conf, operators=[], iou=0.4, max_det=40)
+    boxes, scores, classes, masks = oracle_postprocess(pred, proto, (256, 256), (256, 256), conf, NAMES, 0.4, max_det=40)
+    assert len(boxes) > 0 and masks.shape[0] == len(boxes)
+    assert np.array_equal(out['boxes'], OG.revert_to_origin(boxes, []))
+    assert out['classes'] == classes
+    assert out['masks'].dtype == np.float32 and out['masks'].shape == masks.shape
+    assert OM.mask_iou(out['masks'], masks) >= 0.999
+    assert len(out['segments']) == len(boxes) and all(s.shape[1] == 2 for s in out['segments'])
+    none, _ = seg.predict(frame, 0.999999, operators=[])
+    assert len(none['boxes']) == 0 and len(none['masks']) == 0
+
+
+def test_predict_batch_ragged_frames(models):
+    _, seg = models
+    rng = np.random.default_rng(2)
+    frames = [synth.frames_u8(rng, 1, h, w)[0] for h, w in ((270, 480), (300, 200), (270, 480))]
+    im, ops = seg.letterbox(frames, (256, 256))
+    y = seg.forward(im)
+    pred, proto = y[0].cpu().numpy(), y[1][-1].cpu().numpy()
+    conf = _conf_for(pred)
+    res, _ = seg.predict_batch(frames, conf, imgsz=(256, 256), max_det=30)
+    assert len(res['boxes']) == 3
+    for i, f in enumerate(frames):
+        boxes, scores, classes, masks = oracle_postprocess(pred[i:i + 1], proto[i], (256, 256), f.shape[:2], conf, NAMES, 0.4, max_det=30)
+        assert np.abs(res['boxes'][i] - boxes).max() <= 1e-3 and res['classes'][i] == classes
+        assert res['masks'][i].shape == masks.shape and OM.mask_iou(res['masks'][i], masks) >= 0.999
