@@ -71,11 +71,26 @@ class Pipeline:
         self.lb_out = torch.empty((cfg["batch"], 3, self.S, self.S), dtype=torch.float32, device=frames.device)
         self.mask_out = None
         self.capacity = 0
-        self.ev = None
+        # independent HIP streams: the letterbox of a batch has no data dependence on the post-processing
+        # of the head, so it runs beside the latency-bound NMS kernels instead of in front of them
+        self.side = torch.cuda.Stream(device=frames.device)
 
-    def step(self, time_upsample=None):
+    def step(self, time_upsample=None, time_letterbox=None):
         ops, cfg = self.ops, self.cfg
-        ops.letterbox(self.frames, (self.S, self.S), pad_value=114, swap_rb=True, out=self.lb_out)
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            if time_letterbox is not None:
+                time_letterbox[0].record()
+            ops.letterbox(self.frames, (self.S, self.S), pad_value=114, swap_rb=True, out=self.lb_out)
+            if time_letterbox is not None:
+                time_letterbox[1].record()
+        out = self._post(time_upsample)
+        cur.wait_stream(self.side)
+        return out
+
+    def _post(self, time_upsample=None):
+        ops, cfg = self.ops, self.cfg
         det, count, anchor = ops.nms_v8(self.head, CONF, IOU, nc=cfg["nc"], max_det=MAX_DET)
         fin = ops.finalize_detections(det, count, cfg["nc"], (self.S, self.S), (cfg["h"], cfg["w"]), MASK_CONF)
         masks = None
@@ -161,15 +176,9 @@ def main():
     lb_evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        if proto is None:  # detect workloads: the dominant kernel is the letterbox
-            lb_evs[k][0].record()
-            pipe.ops.letterbox(pipe.frames, (pipe.S, pipe.S), pad_value=114, swap_rb=True, out=pipe.lb_out)
-            lb_evs[k][1].record()
-            det, count, anchor = pipe.ops.nms_v8(pipe.head, CONF, IOU, nc=cfg["nc"], max_det=MAX_DET)
-            fin = pipe.ops.finalize_detections(det, count, cfg["nc"], (pipe.S, pipe.S), (cfg["h"], cfg["w"]), MASK_CONF)
-            out = (det, count, anchor, fin, None)
-        else:
-            out = pipe.step(time_upsample=evs[k])
+        # HIP events go on the stream each kernel is launched on: the upsample on the main stream, the
+        # letterbox (the dominant kernel of the detect workloads) on the side stream
+        out = pipe.step(time_upsample=evs[k] if proto is not None else None, time_letterbox=lb_evs[k])
     barrier()
     elapsed = time.perf_counter() - t0
     det, count, anchor, fin, masks = out

@@ -15,7 +15,8 @@
 //                     against the kept boxes held in LDS, pair masks inside the chunk come from
 //                     wave ballots, one wave resolves the chunk serially with readlane.  Stops
 //                     after max_det keeps (later candidates cannot change earlier keeps).
-//  finalize_kernel    one workgroup: scale/clip boxes in place, per-class threshold, dense ranks.
+//  finalize_boxes_kernel  one workgroup per image: scale/clip boxes in place, per-class threshold, ranks.
+//  finalize_slots_kernel  one workgroup: scan over images -> dense global mask slots and their inverse map.
 #include <cmath>
 
 #include "common.h"
@@ -331,18 +332,17 @@ struct FinalizeParams {
 // Python round(): nearest, ties to even
 __device__ __forceinline__ double py_round(double x) { return rint(x); }
 
-__global__ __launch_bounds__(1024) void finalize_kernel(FinalizeParams F) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int *m_cnt = reinterpret_cast<int *>(smem);        // batch
-  int *m_base = m_cnt + F.batch;                      // batch
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-
-  // one wave per image: boxes, keep flags, in-image ranks
-  for (int b = wave; b < F.batch; b += nwaves) {
-    const int n = min(F.count[b], F.max_det);
-    const int h0 = F.orig_hw ? F.orig_hw[2 * b] : F.uh0;
-    const int w0 = F.orig_hw ? F.orig_hw[2 * b + 1] : F.uw0;
-    // ops.scale_boxes: gain / pad in double (Python floats), applied in fp32
+// grid = batch, block = max_det rounded up to a wave (<= 1024): lane i owns detection i of image b.
+__global__ __launch_bounds__(1024) void finalize_boxes_kernel(FinalizeParams F) {
+  __shared__ int wtot[16];
+  const int b = blockIdx.x;
+  const int i = threadIdx.x, lane = i & 63, wave = i >> 6, nwaves = blockDim.x >> 6;
+  const int n = min(F.count[b], F.max_det);
+  const int h0 = F.orig_hw ? F.orig_hw[2 * b] : F.uh0;
+  const int w0 = F.orig_hw ? F.orig_hw[2 * b + 1] : F.uw0;
+  bool k = false;
+  if (i < n) {
+    // ops.scale_boxes: gain / pad are Python floats (fp64), applied to the fp32 tensor with IEEE division
     const double gh = (double)F.model_h / (double)h0, gw = (double)F.model_w / (double)w0;
     const double gain = gh < gw ? gh : gw;
     double px = ((double)F.model_w - (double)w0 * gain) / 2.0;
@@ -350,55 +350,74 @@ __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeParams F) {
     if (F.pad_round) { px = py_round(px - 0.1); py = py_round(py - 0.1); }
     const float fpx = (float)px, fpy = (float)py, fgain = (float)gain;
     const float fw0 = (float)w0, fh0 = (float)h0;
-    int kept = 0;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-      const int i = i0 + lane;
-      bool k = false;
-      if (i < n) {
-        float *d = F.det + ((size_t)b * F.max_det + i) * F.det_stride;
-        float x1 = d[0], y1 = d[1], x2 = d[2], y2 = d[3];
-        x1 = (x1 - fpx) / fgain; y1 = (y1 - fpy) / fgain;
-        x2 = (x2 - fpx) / fgain; y2 = (y2 - fpy) / fgain;
-        d[0] = fminf(fmaxf(x1, 0.0f), fw0);
-        d[1] = fminf(fmaxf(y1, 0.0f), fh0);
-        d[2] = fminf(fmaxf(x2, 0.0f), fw0);
-        d[3] = fminf(fmaxf(y2, 0.0f), fh0);
-        const float conf = d[4];
-        const int c = (int)d[5];
-        const double t = F.thres ? ((c >= 0 && c < F.nc) ? F.thres[c] : 1.0) : F.uniform_thres;
-        k = (double)conf > t;
-        F.keep[(size_t)b * F.max_det + i] = k ? 1 : 0;
-      }
-      const uint64_t mask = __ballot(k);
-      if (i < n && F.mask_slot)
-        F.mask_slot[(size_t)b * F.max_det + i] = k ? kept + __builtin_popcountll(mask & ((1ull << lane) - 1ull)) : -1;
-      kept += __builtin_popcountll(mask);
+    float *d = F.det + ((size_t)b * F.max_det + i) * F.det_stride;
+    float x1 = d[0], y1 = d[1], x2 = d[2], y2 = d[3];
+    const float conf = d[4];
+    const int c = (int)d[5];
+    x1 = (x1 - fpx) / fgain; y1 = (y1 - fpy) / fgain;
+    x2 = (x2 - fpx) / fgain; y2 = (y2 - fpy) / fgain;
+    d[0] = fminf(fmaxf(x1, 0.0f), fw0);
+    d[1] = fminf(fmaxf(y1, 0.0f), fh0);
+    d[2] = fminf(fmaxf(x2, 0.0f), fw0);
+    d[3] = fminf(fmaxf(y2, 0.0f), fh0);
+    const double t = F.thres ? ((c >= 0 && c < F.nc) ? F.thres[c] : 1.0) : F.uniform_thres;
+    k = (double)conf > t;
+  }
+  const uint64_t mask = __ballot(k);
+  if (lane == 0) wtot[wave] = __builtin_popcountll(mask);
+  __syncthreads();
+  int before = 0, total = 0;
+  for (int w = 0; w < nwaves; ++w) {
+    const int t = wtot[w];
+    if (w < wave) before += t;
+    total += t;
+  }
+  if (i < F.max_det) {
+    F.keep[(size_t)b * F.max_det + i] = k ? 1 : 0;
+    if (F.mask_slot)  // rank inside the image for now; finalize_slots_kernel adds the image's base
+      F.mask_slot[(size_t)b * F.max_det + i] = k ? before + __builtin_popcountll(mask & ((1ull << lane) - 1ull)) : -1;
+  }
+  if (i == 0) F.keep_count[b] = total;
+}
+
+// one workgroup: exclusive scan of keep_count over the images, then global slots and the slot -> (b,i) map
+__global__ __launch_bounds__(1024) void finalize_slots_kernel(FinalizeParams F) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int *m_base = reinterpret_cast<int *>(smem);  // batch
+  int *wtot = m_base + F.batch;                 // one per (round, wave), <= 128 + 1
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rounds = (F.batch + 1023) / 1024;
+  for (int r = 0; r < rounds; ++r) {
+    const int b = r * 1024 + tid;
+    const int v = b < F.batch ? F.keep_count[b] : 0;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
     }
-    // rows beyond count: not kept
-    for (int i = n + lane; i < F.max_det; i += 64) {
-      F.keep[(size_t)b * F.max_det + i] = 0;
-      if (F.mask_slot) F.mask_slot[(size_t)b * F.max_det + i] = -1;
-    }
-    if (lane == 0) { m_cnt[b] = kept; F.keep_count[b] = kept; }
+    if (b < F.batch) m_base[b] = incl - v;  // exclusive inside the wave
+    if (lane == 63) wtot[r * 16 + wave] = incl;
   }
   __syncthreads();
-  // exclusive scan over images (serial: batch is small)
   if (tid == 0) {
     int s = 0;
-    for (int b = 0; b < F.batch; ++b) {
-      m_base[b] = s;
-      if (F.slot_base) F.slot_base[b] = s;
-      s += m_cnt[b];
-    }
-    if (F.slot_base) F.slot_base[F.batch] = s;
+    for (int w = 0; w < rounds * 16; ++w) { const int t = wtot[w]; wtot[w] = s; s += t; }
+    wtot[rounds * 16] = s;
   }
   __syncthreads();
+  for (int b = tid; b < F.batch; b += 1024) {
+    const int base = m_base[b] + wtot[b >> 6];
+    m_base[b] = base;
+    if (F.slot_base) F.slot_base[b] = base;
+  }
+  if (tid == 0 && F.slot_base) F.slot_base[F.batch] = wtot[rounds * 16];
+  __syncthreads();
   if (F.mask_slot) {
-    for (int e = tid; e < F.batch * F.max_det; e += blockDim.x) {
-      const int b = e / F.max_det;
+    for (int e = tid; e < F.batch * F.max_det; e += 1024) {
       const int r = F.mask_slot[e];
       if (r >= 0) {
-        const int slot = m_base[b] + r;
+        const int slot = m_base[e / F.max_det] + r;
         F.mask_slot[e] = slot;
         if (F.slot_map) F.slot_map[slot] = e;
       }
@@ -480,9 +499,15 @@ int lmi_finalize_detections(float *det, const int32_t *count, int batch, int max
   F.model_h = model_h; F.model_w = model_w; F.orig_hw = orig_hw; F.uh0 = uniform_h0; F.uw0 = uniform_w0;
   F.pad_round = pad_round ? 1 : 0; F.thres = thres; F.uniform_thres = uniform_thres; F.keep = keep; F.keep_count = keep_count;
   F.mask_slot = mask_slot; F.slot_map = slot_map; F.slot_base = slot_base;
-  const size_t lds = sizeof(int) * 2 * (size_t)batch + 16;
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), lds, reinterpret_cast<hipStream_t>(stream), F);
-  return lmi_check_launch("finalize_kernel");
+  LMI_REQUIRE(max_det <= LMI_MAX_DET_CAP, LMI_ERR_LIMIT, "lmi_finalize_detections: max_det %d > %d", max_det, LMI_MAX_DET_CAP);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(finalize_boxes_kernel, dim3(batch), dim3((max_det + 63) / 64 * 64), 0, s, F);
+  int rc = lmi_check_launch("finalize_boxes_kernel");
+  if (rc) return rc;
+  if (mask_slot == nullptr && slot_base == nullptr) return LMI_OK;
+  const size_t lds = sizeof(int) * ((size_t)batch + 16 * ((batch + 1023) / 1024) + 1) + 16;
+  hipLaunchKernelGGL(finalize_slots_kernel, dim3(1), dim3(1024), lds, s, F);
+  return lmi_check_launch("finalize_slots_kernel");
 }
 
 }  // extern "C"
