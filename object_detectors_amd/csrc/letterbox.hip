@@ -185,16 +185,18 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
     const void *ubase = reinterpret_cast<const void *>(((uintptr_t)hi << 32) | lo);
     auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ubase), 0,
                                                   __builtin_amdgcn_readfirstlane(frame_bytes), 0x00020000);
-    const int total = 2 * TH * nchunk;
-    for (int idx = tid; idx < total; idx += NT) {
-      const int slot = idx / nchunk, ch = idx - slot * nchunk;
-      const int row = yrow[slot];
-      if (row < 0) continue;
+    // NT / (2*TH) lanes per staged row, each striding over that row's 16-byte chunks
+    constexpr int LPS = NT / (2 * TH);
+    const int slot = tid / LPS;
+    const int row = yrow[slot];
+    if (row >= 0) {
       const uint32_t goff = (uint32_t)((long long)row * stride + span_b0);
       const uint32_t aligned = goff & ~15u;
-      if (ch == 0) yshift[slot] = (int)(goff - aligned);
-      auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, aligned + 16u * ch, 0, 0);
-      *reinterpret_cast<decltype(v) *>(rows + slot * P.pitch + 16 * ch) = v;
+      if ((tid % LPS) == 0) yshift[slot] = (int)(goff - aligned);
+      for (int ch = tid % LPS; ch < nchunk; ch += LPS) {
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, aligned + 16u * ch, 0, 0);
+        *reinterpret_cast<decltype(v) *>(rows + slot * P.pitch + 16 * ch) = v;
+      }
     }
   }
   __syncthreads();
@@ -212,8 +214,11 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
   } else {
     const uint32_t bw = yb[r];
     const int b0 = (int)(bw & 0xffffu), b1 = (int)(bw >> 16);
-    const unsigned char *row0 = rows + (2 * r) * P.pitch + yshift[2 * r];
-    const unsigned char *row1 = rows + (2 * r + 1) * P.pitch + yshift[2 * r + 1];
+    // byte offsets inside the staged-rows region; all LDS accesses below index the one `smem` array so the
+    // compiler keeps them as ds_read (a pointer rebuilt from an integer would turn them into flat loads)
+    const uint32_t *rw = reinterpret_cast<const uint32_t *>(rows);
+    const int base0 = (2 * r) * P.pitch + yshift[2 * r];
+    const int base1 = (2 * r + 1) * P.pitch + yshift[2 * r + 1];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int s = xs[4 * g + k];
@@ -228,11 +233,10 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
       uint32_t px[2][2];  // [row][0: bytes p..p+3, 1: bytes p+4..p+7]
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr) {
-        const unsigned char *p = (rr == 0 ? row0 : row1) + off;
-        const uintptr_t pa = reinterpret_cast<uintptr_t>(p);
-        const uint32_t *q = reinterpret_cast<const uint32_t *>(pa & ~(uintptr_t)3);
-        const uint32_t sh = (uint32_t)(pa & 3);
-        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        const int p = (rr == 0 ? base0 : base1) + off;
+        const int wi = p >> 2;
+        const uint32_t sh = (uint32_t)(p & 3);
+        const uint32_t d0 = rw[wi], d1 = rw[wi + 1], d2 = rw[wi + 2];
         px[rr][0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
         px[rr][1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
       }
