@@ -97,19 +97,23 @@ typedef struct lmi_frame {
  * coefficients, see oracle/cv2_resize.py).
  *   frames_host [host]   lmi_frame[batch]: validated (alignment, strides, geometry) and used to
  *                        size the launch; never dereferenced on the device
- *   frames_dev  [device] the same array in device memory, read by the kernel
+ *   frames_dev  [device] the same array in device memory, read by the kernels
  *   swap_rb != 0 reverses the channel order (BGR<->RGB); pad_value in 0..255.
+ *   workspace   [device] >= lmi_letterbox_workspace_bytes(batch, dst_h, dst_w) bytes, 256-byte
+ *               aligned: the per-frame coefficient tables, rebuilt by every call
  */
+int64_t lmi_letterbox_workspace_bytes(int table_sets, int dst_h, int dst_w);
 int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, int batch,
                      void *dst, int dst_h, int dst_w, int dst_dtype, int pad_value, int swap_rb,
-                     int mode, void *stream);
+                     int mode, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Same, for a batch of equally sized frames stored with a constant image stride: no
- * descriptor array, geometry is derived from (h,w,dst_h,dst_w,stretch) on the host. */
+ * descriptor array, geometry is derived from (h,w,dst_h,dst_w,stretch) on the host; one table
+ * set: workspace >= lmi_letterbox_workspace_bytes(1, dst_h, dst_w). */
 int lmi_letterbox_u8_uniform(const void *src, int batch, int h, int w, int64_t row_stride,
                              int64_t image_stride, void *dst, int dst_h, int dst_w,
                              int dst_dtype, int pad_value, int swap_rb, int stretch, int mode,
-                             void *stream);
+                             void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * NMS -- replaces `ops.non_max_suppression(preds, conf2, iou, agnostic=, max_det=, nc=)`

@@ -34,10 +34,12 @@ SIGNATURES = {
     "lmi_device_count": (C.c_int, []),
     "lmi_preprocess_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "lmi_letterbox_geometry": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
+    "lmi_letterbox_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "lmi_letterbox_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                   C.c_int, C.c_int, C.c_void_p]),
+                                   C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "lmi_letterbox_u8_uniform": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
-                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_int64, C.c_void_p]),
     "lmi_nms_workspace_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "lmi_nms_v8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double, C.c_int, C.c_int,
                              C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -18,6 +18,24 @@ from ._lib import LMI_F16, LMI_F32, LMI_U8, check, lmi_frame
 _L = _lib.load()
 
 
+class _WorkspaceCache:
+    """One growing byte buffer per (device, stream, tag): the library itself never allocates."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, device: torch.device, tag: str, nbytes: int) -> torch.Tensor:
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+        t = self._buf.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=device)
+            self._buf[key] = t
+        return t
+
+
+_ws = _WorkspaceCache()
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -78,8 +96,10 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
         b, h, w, _ = frames.shape
         if out is None:
             out = torch.empty((b, 3, dst_h, dst_w), dtype=tdt, device=frames.device)
+        ws = _ws.get(frames.device, "letterbox", int(_L.lmi_letterbox_workspace_bytes(1, dst_h, dst_w)))
         check(_L.lmi_letterbox_u8_uniform(frames.data_ptr(), b, h, w, frames.stride(1), frames.stride(0), out.data_ptr(),
-                                          dst_h, dst_w, ldt, pad_value, int(swap_rb), int(stretch), 0, _stream()))
+                                          dst_h, dst_w, ldt, pad_value, int(swap_rb), int(stretch), 0, ws.data_ptr(),
+                                          ws.numel(), _stream()))
         g = letterbox_geometry(h, w, dst_h, dst_w, stretch)
         ops = [[{"resize": [g[0], g[1], w, h]}, {"pad": [g[2], g[3], g[4], g[5]]}] for _ in range(b)]
         return out, ops
@@ -107,28 +127,11 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
     ddev = host.to(dev)
     if out is None:
         out = torch.empty((len(keep), 3, dst_h, dst_w), dtype=tdt, device=dev)
+    ws = _ws.get(dev, "letterbox", int(_L.lmi_letterbox_workspace_bytes(len(keep), dst_h, dst_w)))
     check(_L.lmi_letterbox_u8(C.addressof(desc), ddev.data_ptr(), len(keep), out.data_ptr(), dst_h, dst_w, ldt,
-                              pad_value, int(swap_rb), 0, _stream()))
+                              pad_value, int(swap_rb), 0, ws.data_ptr(), ws.numel(), _stream()))
     ddev.record_stream(torch.cuda.current_stream())
     return out, ops
-
-
-class _WorkspaceCache:
-    """One growing byte buffer per (device, tag): the library itself never allocates."""
-
-    def __init__(self):
-        self._buf = {}
-
-    def get(self, device: torch.device, tag: str, nbytes: int) -> torch.Tensor:
-        key = (device.index, tag)
-        t = self._buf.get(key)
-        if t is None or t.numel() < nbytes:
-            t = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=device)
-            self._buf[key] = t
-        return t
-
-
-_ws = _WorkspaceCache()
 
 
 def nms_v8(pred: torch.Tensor, conf_thres: float, iou_thres: float = 0.45, agnostic: bool = False, max_det: int = 300,

@@ -1,7 +1,7 @@
 import os, sys, subprocess, json
 # runs bench-like upsample timing under several knob settings (each in a fresh process: knobs are read at call time anyway)
 import numpy as np, torch
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from object_detectors_amd import hip_ops as ops
 cfg=bench.WORKLOADS['seg640']
