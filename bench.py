@@ -71,28 +71,26 @@ class Pipeline:
         self.lb_out = torch.empty((cfg["batch"], 3, self.S, self.S), dtype=torch.float32, device=frames.device)
         self.mask_out = None
         self.capacity = 0
-        # independent HIP streams: the letterbox of a batch has no data dependence on the post-processing
-        # of the head, so it runs beside the latency-bound NMS kernels instead of in front of them
-        self.side = torch.cuda.Stream(device=frames.device)
+        self.nms_out = None
+        self.fin_out = None
 
     def step(self, time_upsample=None, time_letterbox=None):
-        ops, cfg = self.ops, self.cfg
-        cur = torch.cuda.current_stream()
-        self.side.wait_stream(cur)
-        with torch.cuda.stream(self.side):
-            if time_letterbox is not None:
-                time_letterbox[0].record()
-            ops.letterbox(self.frames, (self.S, self.S), pad_value=114, swap_rb=True, out=self.lb_out)
-            if time_letterbox is not None:
-                time_letterbox[1].record()
-        out = self._post(time_upsample)
-        cur.wait_stream(self.side)
-        return out
+        """One pass of the hot path over the batch, all on the current stream.  (Running the letterbox on a
+        second stream beside the NMS chain was measured and bought nothing: the kernels serialise on the
+        chip -- the NMS workgroups starve behind the letterbox's -- so the simple order stays.)"""
+        ops = self.ops
+        if time_letterbox is not None:
+            time_letterbox[0].record()
+        ops.letterbox(self.frames, (self.S, self.S), pad_value=114, swap_rb=True, out=self.lb_out)
+        if time_letterbox is not None:
+            time_letterbox[1].record()
+        return self._post(time_upsample)
 
     def _post(self, time_upsample=None):
         ops, cfg = self.ops, self.cfg
-        det, count, anchor = ops.nms_v8(self.head, CONF, IOU, nc=cfg["nc"], max_det=MAX_DET)
-        fin = ops.finalize_detections(det, count, cfg["nc"], (self.S, self.S), (cfg["h"], cfg["w"]), MASK_CONF)
+        self.nms_out = ops.nms_v8(self.head, CONF, IOU, nc=cfg["nc"], max_det=MAX_DET, out=self.nms_out)
+        det, count, anchor = self.nms_out
+        self.fin_out = fin = ops.finalize_detections(det, count, cfg["nc"], (self.S, self.S), (cfg["h"], cfg["w"]), MASK_CONF, out=self.fin_out)
         masks = None
         if self.proto is not None:
             if self.mask_out is None:  # first pass: size the mask buffer from the (deterministic) survivor count
@@ -140,6 +138,8 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=64, help="at most this many images of the workload are timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="stop the CPU sample after this much wall time")
     ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per step in the timed region "
+                    "(the per-kernel roofline timing then comes from an eager, event-timed pass right after it)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -174,13 +174,27 @@ def main():
     barrier()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     lb_evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    graph = None
+    if args.graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = pipe.step()
+        graph.replay()
+        barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        # HIP events go on the stream each kernel is launched on: the upsample on the main stream, the
-        # letterbox (the dominant kernel of the detect workloads) on the side stream
-        out = pipe.step(time_upsample=evs[k] if proto is not None else None, time_letterbox=lb_evs[k])
+        if graph is not None:
+            graph.replay()
+        else:
+            # HIP events go on the stream each kernel is launched on: the upsample on the main stream, the
+            # letterbox (the dominant kernel of the detect workloads) on the side stream
+            out = pipe.step(time_upsample=evs[k] if proto is not None else None, time_letterbox=lb_evs[k])
     barrier()
     elapsed = time.perf_counter() - t0
+    if graph is not None:   # events cannot be recorded inside a captured graph: time the kernel in eager passes
+        for k in range(args.steps):
+            pipe.step(time_upsample=evs[k] if proto is not None else None, time_letterbox=lb_evs[k])
+        barrier()
     det, count, anchor, fin, masks = out
     n_surv = int(fin["keep_count"].sum().item())
     n_kept = int(count.sum().item())
@@ -235,7 +249,7 @@ def main():
             "config": {"workload": cfg["desc"], "name": args.workload, "per_gpu_batch": B, "conf": CONF, "iou": IOU,
                        "max_det": MAX_DET, "survivors_per_batch": n_surv, "nms_kept_per_batch": n_kept,
                        "per_rank": [{"images": int(r["images"]), "survivors": int(r["survivors"]), "kept_checksum": (int(r["chk_hi"]) << 31) | int(r["chk_lo"])} for r in reports],
-                       "mask_dtype": "uint8", "forward": "excluded", "sharding": f"{world} x independent batches, no collective on the hot path"},
+                       "mask_dtype": "uint8", "forward": "excluded", "launch": "hip graph replay" if args.graph else "eager", "sharding": f"{world} x independent batches, no collective on the hot path"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(res), flush=True)

@@ -40,6 +40,16 @@ struct GemmParams {
   int tiles_per_block;  // pixel tiles (32 px) per wave
 };
 
+// aten upsample_bilinear2d, align_corners=False: source index / weights of output index d
+__device__ __forceinline__ void bilinear_src(float scale, int d, int in_n, int &i0, int &i1, float &l0, float &l1) {
+  float s = scale * ((float)d + 0.5f) - 0.5f;
+  s = fmaxf(s, 0.0f);
+  i0 = (int)s;
+  i1 = i0 + ((i0 < in_n - 1) ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.0f - l1;
+}
+
 // grid: x = pixel-tile groups, y = survivor tile (32 slots), z = image
 __global__ __launch_bounds__(256) void mask_gemm_kernel(GemmParams G) {
   const int b = blockIdx.z;
@@ -49,6 +59,39 @@ __global__ __launch_bounds__(256) void mask_gemm_kernel(GemmParams G) {
   if (row0 >= m_b) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wh = G.g.bottom - G.g.top;
+
+  // Logits rows each survivor's upsample will read: the bilinear taps of the output rows inside its box
+  // (same arithmetic as mask_upsample_kernel).  Only those are computed and written.
+  __shared__ int rlo[32], rhi[32], runion[2];
+  if (threadIdx.x < 32) {
+    int lo = 1, hi = 0;
+    const int i = row0 + (int)threadIdx.x;
+    if (i < m_b) {
+      const float *d = G.det + (size_t)G.slot_map[base + i] * G.det_stride;
+      const float bx1 = d[0], by1 = d[1], bx2 = d[2], by2 = d[3];
+      const int ya = max(0, (int)ceilf(by1)), yb = min(G.g.h0, (int)ceilf(by2));
+      if (ya < yb && bx1 < bx2) {
+        const float scale_h = (float)wh / (float)G.g.h0;
+        int i0, i1; float l0, l1;
+        bilinear_src(scale_h, ya, wh, i0, i1, l0, l1);
+        lo = i0;
+        bilinear_src(scale_h, yb - 1, wh, i0, i1, l0, l1);
+        hi = i1;
+      }
+    }
+    rlo[threadIdx.x] = lo;
+    rhi[threadIdx.x] = hi;
+    // union over the tile's survivors (wave 0, lanes 0..31 active)
+    int ulo = lo <= hi ? lo : 0x7fffffff, uhi = lo <= hi ? hi : -1;
+    for (int o = 16; o > 0; o >>= 1) {
+      ulo = min(ulo, __shfl_xor(ulo, o));
+      uhi = max(uhi, __shfl_xor(uhi, o));
+    }
+    if (threadIdx.x == 0) { runion[0] = ulo; runion[1] = uhi; }
+  }
+  __syncthreads();
+  const int ulo = runion[0], uhi = runion[1];
+  if (ulo > uhi) return;
   const int npx = wh * G.g.mw;
   const int plane = G.g.mh * G.g.mw;
   const float *pb = G.proto + (size_t)b * 32 * plane + (size_t)G.g.top * G.g.mw;
@@ -70,8 +113,10 @@ __global__ __launch_bounds__(256) void mask_gemm_kernel(GemmParams G) {
   for (int t = 0; t < G.tiles_per_block; ++t) {
     const int p0 = (tile0 + t) * 32;
     if (p0 >= npx) break;
+    if (p0 / G.g.mw > uhi || min(p0 + 31, npx - 1) / G.g.mw < ulo) continue;  // no survivor of this tile reads these rows
     const int p = p0 + (lane & 31);
     const bool pv = p < npx;
+    const int prow = p / G.g.mw;
     floatx16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float bf[16];
 #pragma unroll
@@ -84,7 +129,8 @@ __global__ __launch_bounds__(256) void mask_gemm_kernel(GemmParams G) {
       for (int r = 0; r < 16; ++r) {
         const int i = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const long long slot = (long long)base + i;
-        if (i < m_b && slot < G.capacity) G.logits[(size_t)slot * npx + p] = acc[r];
+        const int li = i - row0;
+        if (i < m_b && slot < G.capacity && prow >= rlo[li] && prow <= rhi[li]) G.logits[(size_t)slot * npx + p] = acc[r];
       }
     }
   }
@@ -102,7 +148,6 @@ struct UpParams {
   int rows_per_block;
   int lds_rows;  // logits rows the LDS buffer can hold
   int *overflow;
-  int nt;
 };
 
 template <typename OutT>
@@ -144,16 +189,6 @@ struct MaskOut<float> {
   static __device__ __forceinline__ void store_vec_nt(float *p, const uint32_t bits) { store_vec(p, bits); }
   static __device__ __forceinline__ void store1(float *p, bool on) { *p = on ? 1.0f : 0.0f; }
 };
-
-// aten upsample_bilinear2d, align_corners=False: source index / weights of output index d
-__device__ __forceinline__ void bilinear_src(float scale, int d, int in_n, int &i0, int &i1, float &l0, float &l1) {
-  float s = scale * ((float)d + 0.5f) - 0.5f;
-  s = fmaxf(s, 0.0f);
-  i0 = (int)s;
-  i1 = i0 + ((i0 < in_n - 1) ? 1 : 0);
-  l1 = s - (float)i0;
-  l0 = 1.0f - l1;
-}
 
 // grid: x = row strips, y = slot
 template <typename OutT>
@@ -229,7 +264,7 @@ __global__ __launch_bounds__(256) void mask_upsample_kernel(UpParams U) {
       }
     }
     if (vec_ok) {
-      if (U.nt) MO::store_vec_nt(p, bits); else MO::store_vec(p, bits);
+      MO::store_vec_nt(p, bits);  // streaming stores: masks are written once, never re-read here (+2 % measured)
     } else {
       for (int k = 0; k < PX && x0 + k < W0; ++k) MO::store1(p + k, (bits >> k) & 1u);
     }
@@ -317,7 +352,6 @@ int lmi_mask_upsample(const void *workspace, int batch, int nm, int mh, int mw, 
   }
   LMI_REQUIRE((size_t)lds_rows * ww * sizeof(float) <= 64 * 1024, LMI_ERR_LIMIT, "lmi_mask_upsample: prototype rows too wide for LDS (%d)", ww);
   U.rows_per_block = rpb; U.lds_rows = lds_rows;
-  U.nt = 1;  // streaming (non-temporal) stores: the masks are written once and never re-read here (+2 % measured)
   const size_t lds = (size_t)lds_rows * ww * sizeof(float);
   dim3 ugrid((h0 + rpb - 1) / rpb, (unsigned)capacity_masks);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -24,7 +24,8 @@
 namespace {
 
 constexpr int kSortThreads = 1024;
-constexpr int kSortLdsCap = 16384;  // keys that fit the LDS sort buffer
+constexpr int kSortLdsCap = 4096;  // keys sorted inside LDS (32 KiB, so the workgroup can share a CU with other kernels' blocks);
+                                   // more candidates than that are sorted in the global workspace
 
 __host__ __device__ inline int next_pow2(int v) {
   int p = 1;
@@ -62,25 +63,33 @@ NmsLayout nms_layout(int batch, int anchors) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Workgroup = 4 waves over the SAME 64*VEC anchors; wave w scans one quarter of the class rows (4x the loads in
+// flight of a one-wave-per-anchor-group layout), wave 0 merges the quarters in class order (strict >, so the
+// first maximal class wins as in torch.max) and compacts the candidates.
 template <int VEC>
 __global__ __launch_bounds__(256) void nms_decode_filter(const float *__restrict__ pred, int nc, int nm, int A, float conf,
                                                         uint64_t *__restrict__ keys, int P, int *__restrict__ cls_of,
                                                         int *__restrict__ cand_count) {
+  __shared__ float sbest[3][64 * VEC];
+  __shared__ int sidx[3][64 * VEC];
   const int b = blockIdx.y;
-  const int a0 = (blockIdx.x * 256 + threadIdx.x) * VEC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int a0 = (blockIdx.x * 64 + lane) * VEC;
   const int C = 4 + nc + nm;
   const float *cls = pred + ((size_t)b * C + 4) * A;
+  const int cpart = (nc + 3) >> 2;
+  const int c0 = wave * cpart, c1 = min(nc, c0 + cpart);
   float best[VEC];
   int bi[VEC];
-  bool valid = a0 < A;
+  const bool valid = a0 < A;
 #pragma unroll
-  for (int k = 0; k < VEC; ++k) { best[k] = -INFINITY; bi[k] = 0; }
-  if (valid) {
+  for (int k = 0; k < VEC; ++k) { best[k] = -INFINITY; bi[k] = c0; }
+  if (valid && c0 < c1) {
     if constexpr (VEC == 4) {
-      float4 v = *reinterpret_cast<const float4 *>(cls + a0);
+      float4 v = *reinterpret_cast<const float4 *>(cls + (size_t)c0 * A + a0);
       best[0] = v.x; best[1] = v.y; best[2] = v.z; best[3] = v.w;
 #pragma unroll 8
-      for (int c = 1; c < nc; ++c) {
+      for (int c = c0 + 1; c < c1; ++c) {
         v = *reinterpret_cast<const float4 *>(cls + (size_t)c * A + a0);
         const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -88,14 +97,27 @@ __global__ __launch_bounds__(256) void nms_decode_filter(const float *__restrict
           if (e[k] > best[k]) { best[k] = e[k]; bi[k] = c; }
       }
     } else {
-      best[0] = cls[a0];
+      best[0] = cls[(size_t)c0 * A + a0];
 #pragma unroll 8
-      for (int c = 1; c < nc; ++c) {
+      for (int c = c0 + 1; c < c1; ++c) {
         const float e = cls[(size_t)c * A + a0];
         if (e > best[0]) { best[0] = e; bi[0] = c; }
       }
     }
   }
+  if (wave > 0) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { sbest[wave - 1][lane * VEC + k] = best[k]; sidx[wave - 1][lane * VEC + k] = bi[k]; }
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const float e = sbest[w][lane * VEC + k];
+      if (e > best[k]) { best[k] = e; bi[k] = sidx[w][lane * VEC + k]; }
+    }
   int cnt = 0;
   bool flag[VEC];
 #pragma unroll
@@ -103,8 +125,7 @@ __global__ __launch_bounds__(256) void nms_decode_filter(const float *__restrict
     flag[k] = valid && (a0 + k < A) && (best[k] > conf);
     cnt += flag[k] ? 1 : 0;
   }
-  // wave-level exclusive scan of cnt
-  const int lane = threadIdx.x & 63;
+  // wave-level exclusive scan of cnt, one atomic per wave
   int incl = cnt;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -460,10 +481,10 @@ int lmi_nms_v8(const float *pred, int batch, int nc, int nm, int anchors, float 
   if (e != hipSuccess) { lmi_set_error("lmi_nms_v8: hipMemsetAsync: %s", hipGetErrorString(e)); return LMI_ERR_LAUNCH; }
 
   if ((anchors & 3) == 0) {
-    dim3 grid((anchors / 4 + 255) / 256, batch);
+    dim3 grid((anchors / 4 + 63) / 64, batch);
     hipLaunchKernelGGL(nms_decode_filter<4>, grid, dim3(256), 0, s, pred, nc, nm, anchors, conf_thres, keys, L.P, cls_of, cand_count);
   } else {
-    dim3 grid((anchors + 255) / 256, batch);
+    dim3 grid((anchors + 63) / 64, batch);
     hipLaunchKernelGGL(nms_decode_filter<1>, grid, dim3(256), 0, s, pred, nc, nm, anchors, conf_thres, keys, L.P, cls_of, cand_count);
   }
   int rc = lmi_check_launch("nms_decode_filter");

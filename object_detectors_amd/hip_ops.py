@@ -135,11 +135,12 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
 
 
 def nms_v8(pred: torch.Tensor, conf_thres: float, iou_thres: float = 0.45, agnostic: bool = False, max_det: int = 300,
-           nc: int = 0, max_nms: int = 30000, max_wh: float = 7680.0):
+           nc: int = 0, max_nms: int = 30000, max_wh: float = 7680.0, out=None):
     """`ops.non_max_suppression` on the head output (B, 4+nc+nm, A) fp32.
 
     Returns (det (B,max_det,6+nm) fp32, count (B,) int32, anchor (B,max_det) int32), all on the
-    device; rows >= count[b] are unspecified."""
+    device; rows >= count[b] are unspecified.  `out` = a previous result tuple of the same shapes
+    to write into instead of allocating (serving loops)."""
     _need_cuda(pred, "pred")
     if pred.dtype != torch.float32:
         pred = pred.float()
@@ -150,9 +151,14 @@ def nms_v8(pred: torch.Tensor, conf_thres: float, iou_thres: float = 0.45, agnos
     nm = ch - nc - 4
     if nm < 0:
         raise ValueError(f"nc={nc} does not fit a head with {ch} channels")
-    det = torch.empty((b, max_det, 6 + nm), dtype=torch.float32, device=pred.device)
-    count = torch.empty((b,), dtype=torch.int32, device=pred.device)
-    anchor = torch.empty((b, max_det), dtype=torch.int32, device=pred.device)
+    if out is not None:
+        det, count, anchor = out
+        if det.shape != (b, max_det, 6 + nm) or count.shape != (b,) or anchor.shape != (b, max_det):
+            raise ValueError("nms_v8: `out` buffers do not match this call's shapes")
+    else:
+        det = torch.empty((b, max_det, 6 + nm), dtype=torch.float32, device=pred.device)
+        count = torch.empty((b,), dtype=torch.int32, device=pred.device)
+        anchor = torch.empty((b, max_det), dtype=torch.int32, device=pred.device)
     nbytes = int(_L.lmi_nms_workspace_bytes(b, a))
     ws = _ws.get(pred.device, "nms", nbytes)
     check(_L.lmi_nms_v8(pred.data_ptr(), b, nc, nm, a, float(conf_thres), float(iou_thres), int(agnostic), int(max_det),
@@ -163,7 +169,7 @@ def nms_v8(pred: torch.Tensor, conf_thres: float, iou_thres: float = 0.45, agnos
 
 def finalize_detections(det: torch.Tensor, count: torch.Tensor, nc: int, model_hw: Tuple[int, int],
                         orig_hw: Union[Tuple[int, int], torch.Tensor], thres: Union[float, torch.Tensor],
-                        pad_round: bool = True, with_slots: bool = True):
+                        pad_round: bool = True, with_slots: bool = True, out=None):
     """scale_boxes + clip IN PLACE on det[..., :4], per-class threshold, dense survivor ranks.
 
     orig_hw: (H0, W0) for every image, or an int32 device tensor (B,2).  thres: a float, or a
@@ -172,11 +178,17 @@ def finalize_detections(det: torch.Tensor, count: torch.Tensor, nc: int, model_h
     _need_cuda(det, "det")
     b, max_det, stride = det.shape
     dev = det.device
-    keep = torch.empty((b, max_det), dtype=torch.uint8, device=dev)
-    keep_count = torch.empty((b,), dtype=torch.int32, device=dev)
-    mask_slot = torch.empty((b, max_det), dtype=torch.int32, device=dev) if with_slots else None
-    slot_map = torch.empty((b * max_det,), dtype=torch.int32, device=dev) if with_slots else None
-    slot_base = torch.empty((b + 1,), dtype=torch.int32, device=dev) if with_slots else None
+    if out is not None:   # reuse a previous result dict of the same shapes
+        keep, keep_count = out["keep"], out["keep_count"]
+        mask_slot, slot_map, slot_base = out["mask_slot"], out["slot_map"], out["slot_base"]
+        if keep.shape != (b, max_det):
+            raise ValueError("finalize_detections: `out` buffers do not match this call's shapes")
+    else:
+        keep = torch.empty((b, max_det), dtype=torch.uint8, device=dev)
+        keep_count = torch.empty((b,), dtype=torch.int32, device=dev)
+        mask_slot = torch.empty((b, max_det), dtype=torch.int32, device=dev) if with_slots else None
+        slot_map = torch.empty((b * max_det,), dtype=torch.int32, device=dev) if with_slots else None
+        slot_base = torch.empty((b + 1,), dtype=torch.int32, device=dev) if with_slots else None
     if isinstance(orig_hw, torch.Tensor):
         _need_cuda(orig_hw, "orig_hw")
         ohw = orig_hw.to(torch.int32).contiguous()
