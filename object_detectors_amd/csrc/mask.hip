@@ -14,8 +14,6 @@
 //                        strip needs in LDS, then bilinear (align_corners=False) -> box crop ->
 //                        `> 0`, 16 bytes per lane per store.  HBM-write-bound: m*H0*W0 bytes of
 //                        uint8 per image are written exactly once (zeros outside the box included).
-#include <cstdlib>
-
 #include "common.h"
 
 namespace {
@@ -37,7 +35,7 @@ struct GemmParams {
   int batch, max_det, det_stride;
   long long capacity;
   MaskGeom g;
-  int tiles_per_block;  // pixel tiles (32 px) per wave
+  int tiles_per_block;  // pixel tiles (32*V px) per wave
 };
 
 // aten upsample_bilinear2d, align_corners=False: source index / weights of output index d
@@ -51,6 +49,7 @@ __device__ __forceinline__ void bilinear_src(float scale, int d, int in_n, int &
 }
 
 // grid: x = pixel-tile groups, y = survivor tile (32 slots), z = image
+template <int V>
 __global__ __launch_bounds__(256) void mask_gemm_kernel(GemmParams G) {
   const int b = blockIdx.z;
   const int base = G.slot_base[b];
@@ -109,28 +108,50 @@ __global__ __launch_bounds__(256) void mask_gemm_kernel(GemmParams G) {
     for (int s = 0; s < 16; ++s) a[s] = c ? c[2 * s + (lane >> 5)] : 0.0f;
   }
 
+  // Tile = 32 survivors x 32*V pixels.  With V = 4 a lane owns 4 ADJACENT pixels (one 16-byte load per k row, one
+  // 16-byte store per survivor row) and the 4 MFMA chains e = 0..3 use pixel 4n+e as column n: 16 KiB of loads
+  // in flight per wave instead of 4 KiB.
+  constexpr int TP = 32 * V;
   const int tile0 = (blockIdx.x * 4 + wave) * G.tiles_per_block;
   for (int t = 0; t < G.tiles_per_block; ++t) {
-    const int p0 = (tile0 + t) * 32;
+    const int p0 = (tile0 + t) * TP;
     if (p0 >= npx) break;
-    if (p0 / G.g.mw > uhi || min(p0 + 31, npx - 1) / G.g.mw < ulo) continue;  // no survivor of this tile reads these rows
-    const int p = p0 + (lane & 31);
-    const bool pv = p < npx;
+    if (p0 / G.g.mw > uhi || min(p0 + TP - 1, npx - 1) / G.g.mw < ulo) continue;  // no survivor of this tile reads these rows
+    const int p = p0 + V * (lane & 31);
+    const bool pv = p < npx;          // npx % V == 0: a lane's V pixels are valid together and share a row
     const int prow = p / G.g.mw;
-    floatx16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float bf[16];
+    floatx16 acc[V];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) bf[s] = pv ? pb[(size_t)(2 * s + (lane >> 5)) * plane + p] : 0.0f;
+    for (int e = 0; e < V; ++e)
 #pragma unroll
-    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bf[s], acc, 0, 0, 0);
-    // D: col (pixel) = lane&31 ; row (survivor) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+      for (int r = 0; r < 16; ++r) acc[e][r] = 0.0f;
+    float bf[16][V];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float *q = pb + (size_t)(2 * s + (lane >> 5)) * plane + p;
+      if constexpr (V == 4) {
+        const float4 v = pv ? *reinterpret_cast<const float4 *>(q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bf[s][0] = v.x; bf[s][1] = v.y; bf[s][2] = v.z; bf[s][3] = v.w;
+      } else {
+        bf[s][0] = pv ? *q : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bf[s][e], acc[e], 0, 0, 0);
+    // D: col n = lane&31 (pixel V*n+e of the tile) ; row (survivor) = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (pv) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int i = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int li = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int i = row0 + li;
         const long long slot = (long long)base + i;
-        const int li = i - row0;
-        if (i < m_b && slot < G.capacity && prow >= rlo[li] && prow <= rhi[li]) G.logits[(size_t)slot * npx + p] = acc[r];
+        if (i < m_b && slot < G.capacity && prow >= rlo[li] && prow <= rhi[li]) {
+          float *o = G.logits + (size_t)slot * npx + p;
+          if constexpr (V == 4) *reinterpret_cast<float4 *>(o) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+          else *o = acc[0][r];
+        }
       }
     }
   }
@@ -320,11 +341,13 @@ int lmi_mask_logits(const float *proto, int batch, int nm, int mh, int mw, const
   G.proto = proto; G.det = det; G.slot_map = slot_map; G.slot_base = slot_base; G.logits = reinterpret_cast<float *>(workspace);
   G.batch = batch; G.max_det = max_det; G.det_stride = det_stride; G.capacity = capacity_masks; G.g = g;
   const int npx = (g.bottom - g.top) * mw;
-  const int ntiles = (npx + 31) / 32;
-  G.tiles_per_block = 4;
+  const bool vec4 = (mw % 4) == 0 && lmi_is_aligned(proto, 16);   // rows of the window start 16-byte aligned
+  const int ntiles = (npx + (vec4 ? 127 : 31)) / (vec4 ? 128 : 32);
+  G.tiles_per_block = vec4 ? 1 : 4;
   const int gx = (ntiles + 4 * G.tiles_per_block - 1) / (4 * G.tiles_per_block);
   dim3 ggrid(gx, (max_det + 31) / 32, batch);
-  hipLaunchKernelGGL(mask_gemm_kernel, ggrid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
+  if (vec4) hipLaunchKernelGGL(mask_gemm_kernel<4>, ggrid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
+  else hipLaunchKernelGGL(mask_gemm_kernel<1>, ggrid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
   return lmi_check_launch("mask_gemm_kernel");
 }
 
