@@ -5,11 +5,11 @@
 // object_detectors/yolov5_lmi/trt/yolov5_trt.py:373-415).  Semantics: oracle/masks.py.
 //
 // Kernels
-//  mask_gemm_kernel      logits[slot][y][x] = sum_k coef[slot][k] * proto[b][k][y][x] for the rows
-//                        of the letterbox crop window only, on the exact-fp32 MFMA
-//                        (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain).  A = 32 survivors x K,
-//                        B = K x 32 pixels (two 128-byte row segments per wave load), D rows are
-//                        written as 128-byte segments.  Tiny: 2*m*32*mh*mw flop per image.
+//  mask_logits_rows_kernel  logits[slot][y][x] = sum_k coef[slot][k] * proto[b][k][y][x], only for the rows
+//                        of the letterbox crop window that lie under the survivor's box, as a k-ordered
+//                        fmaf chain on the vector ALU (v_pk_fma_f32); proto is read once.
+//  mask_gemm_kernel      the same product as dense 32-survivor tiles on the exact-fp32 MFMA
+//                        (v_mfma_f32_32x32x2_f32); kept for odd prototype widths.
 //  mask_upsample_kernel  per survivor, per strip of output rows: stages the few logits rows the
 //                        strip needs in LDS, then bilinear (align_corners=False) -> box crop ->
 //                        `> 0`, 16 bytes per lane per store.  HBM-write-bound: m*H0*W0 bytes of
@@ -153,6 +153,97 @@ __global__ __launch_bounds__(256) void mask_gemm_kernel(GemmParams G) {
           else *o = acc[0][r];
         }
       }
+    }
+  }
+}
+
+// Row-sparse variant of the GEMM on the vector ALU, used when prototype rows are whole 8-byte pairs.
+// A survivor's upsample reads only the logits rows under its box, typically a tenth of the window, so the dense
+// 32-survivor MFMA tile above spends most of its issue slots on rows nobody reads (measured 82 us per seg640
+// launch, MFMA-issue bound).  Here a wave keeps 128 consecutive window pixels x 32 channels in registers (2 px per
+// lane) and walks the image's survivors, doing the k-ordered fmaf chain only for those whose row range meets the
+// wave's pixels; coefficients and row ranges sit in LDS and are read as broadcasts.
+// grid: x = groups of 4 pixel tiles (one per wave), y = image
+constexpr int kSurvBatch = 128;  // survivors staged per pass: 128 * (32 coef + 2 range) * 4 B = 17 KiB of LDS
+
+__global__ __launch_bounds__(256) void mask_logits_rows_kernel(GemmParams G) {
+  typedef float float2v __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) float coef[kSurvBatch][32];
+  __shared__ int rlo[kSurvBatch], rhi[kSurvBatch];
+
+  const int b = blockIdx.y;
+  const int base = G.slot_base[b];
+  const int m_b = G.slot_base[b + 1] - base;
+  if (m_b <= 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wh = G.g.bottom - G.g.top, mw = G.g.mw;
+  const int npx = wh * mw;
+  const int plane = G.g.mh * mw;
+  const float *pb = G.proto + (size_t)b * 32 * plane + (size_t)G.g.top * mw;
+  const float scale_h = (float)wh / (float)G.g.h0;
+
+  const int p0 = (blockIdx.x * 4 + wave) * 128;
+  const int p = p0 + 2 * lane;
+  const bool pv = p < npx;                 // mw even: a lane's two pixels are valid together and share a row
+  const int prow = pv ? p / mw : -1;
+  const int ra = p0 < npx ? p0 / mw : 0x7fffffff;   // rows this wave touches
+  const int rb = p0 < npx ? min(p0 + 127, npx - 1) / mw : -1;
+
+  auto row_range = [&](const float *d, int &lo, int &hi) {
+    const float bx1 = d[0], by1 = d[1], bx2 = d[2], by2 = d[3];
+    lo = 1; hi = 0;
+    const int ya = max(0, (int)ceilf(by1)), yb = min(G.g.h0, (int)ceilf(by2));
+    if (ya < yb && bx1 < bx2) {  // same arithmetic as mask_upsample_kernel
+      int i0, i1; float l0, l1;
+      bilinear_src(scale_h, ya, wh, i0, i1, l0, l1);
+      lo = i0;
+      bilinear_src(scale_h, yb - 1, wh, i0, i1, l0, l1);
+      hi = i1;
+    }
+  };
+
+  // Issued before anything depends on the survivor list, so the loads overlap the staging below.  Rows nobody
+  // reads are loaded too: with ~47 boxes per image nearly every window row is under some box.
+  float2v bf[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const float2v z = {0.0f, 0.0f};
+    bf[k] = pv ? *reinterpret_cast<const float2v *>(pb + (size_t)k * plane + p) : z;
+  }
+
+  for (int s0 = 0; s0 < m_b; s0 += kSurvBatch) {
+    const int ns = min(kSurvBatch, m_b - s0);
+    __syncthreads();  // the previous batch's readers are done
+    // stage coefficients (one 128-byte row per survivor) and row ranges
+    for (int idx = threadIdx.x; idx < ns * 32; idx += 256) {
+      const int i = idx >> 5, k = idx & 31;
+      coef[i][k] = G.det[(size_t)G.slot_map[base + s0 + i] * G.det_stride + 6 + k];
+    }
+    if (threadIdx.x < ns) {
+      int lo, hi;
+      row_range(G.det + (size_t)G.slot_map[base + s0 + threadIdx.x] * G.det_stride, lo, hi);
+      rlo[threadIdx.x] = lo;
+      rhi[threadIdx.x] = hi;
+    }
+    __syncthreads();
+
+    for (int i = 0; i < ns; ++i) {
+      const int lo = rlo[i], hi = rhi[i];
+      if (hi < ra || lo > rb) continue;  // wave-uniform
+      const long long slot = (long long)base + s0 + i;
+      if (slot >= G.capacity) continue;
+      float2v acc = {0.0f, 0.0f};
+#pragma unroll
+      for (int k4 = 0; k4 < 8; ++k4) {
+        const float4 c = *reinterpret_cast<const float4 *>(&coef[i][4 * k4]);
+        const float cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float2v cv = {cc[j], cc[j]};
+          acc = __builtin_elementwise_fma(cv, bf[4 * k4 + j], acc);
+        }
+      }
+      if (prow >= lo && prow <= hi) *reinterpret_cast<float2v *>(G.logits + (size_t)slot * npx + p) = acc;
     }
   }
 }
@@ -341,13 +432,17 @@ int lmi_mask_logits(const float *proto, int batch, int nm, int mh, int mw, const
   G.proto = proto; G.det = det; G.slot_map = slot_map; G.slot_base = slot_base; G.logits = reinterpret_cast<float *>(workspace);
   G.batch = batch; G.max_det = max_det; G.det_stride = det_stride; G.capacity = capacity_masks; G.g = g;
   const int npx = (g.bottom - g.top) * mw;
-  const bool vec4 = (mw % 4) == 0 && lmi_is_aligned(proto, 16);   // rows of the window start 16-byte aligned
-  const int ntiles = (npx + (vec4 ? 127 : 31)) / (vec4 ? 128 : 32);
-  G.tiles_per_block = vec4 ? 1 : 4;
+  if ((mw % 2) == 0 && lmi_is_aligned(proto, 8)) {
+    const int tiles = (npx + 127) / 128;
+    hipLaunchKernelGGL(mask_logits_rows_kernel, dim3((tiles + 3) / 4, batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
+    return lmi_check_launch("mask_logits_rows_kernel");
+  }
+  // odd prototype width: dense MFMA tiles, one pixel per lane
+  const int ntiles = (npx + 31) / 32;
+  G.tiles_per_block = 4;
   const int gx = (ntiles + 4 * G.tiles_per_block - 1) / (4 * G.tiles_per_block);
   dim3 ggrid(gx, (max_det + 31) / 32, batch);
-  if (vec4) hipLaunchKernelGGL(mask_gemm_kernel<4>, ggrid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
-  else hipLaunchKernelGGL(mask_gemm_kernel<1>, ggrid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
+  hipLaunchKernelGGL(mask_gemm_kernel<1>, ggrid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
   return lmi_check_launch("mask_gemm_kernel");
 }
 

@@ -27,6 +27,7 @@ WIDE_READS = {
     "finalize_boxes_kernel": False,
     "finalize_slots_kernel": False,
     "mask_gemm_kernel": True,        # float4 loads of the prototype planes
+    "mask_logits_rows_kernel": False,  # 8 B per lane loads of the prototype planes (uncalibrated width)
     "mask_upsample_kernel": False,   # dword loads of logits rows (small beside the writes)
 }
 

@@ -263,13 +263,16 @@ def test_finalize_scale_clip_threshold(ops, h0, w0, S):
 
 # ---------------------------------------------------------------- masks (a7)
 @pytest.mark.parametrize("h0,w0,S,out_dtype", [(270, 480, 160, torch.uint8), (1080, 1920, 640, torch.uint8), (375, 500, 640, torch.float32),
-                                                 (101, 67, 160, torch.uint8), (640, 640, 640, torch.uint8)])
+                                                 (101, 67, 160, torch.uint8), (640, 640, 640, torch.uint8),
+                                                 (90, 120, 100, torch.uint8),      # 25x25 prototypes: odd width -> MFMA tile kernel
+                                                 (240, 320, 320, torch.uint8)])    # 200 + 150 survivors: several staging batches
 def test_process_mask_iou(ops, h0, w0, S, out_dtype):
     rng = np.random.default_rng(h0 * 3 + w0)
-    B, nc, nm, max_det = 2, 4, 32, 24
+    many = (h0, w0) == (240, 320)
+    B, nc, nm, max_det = 2, 4, 32, (256 if many else 24)
     mh = mw = S // 4
     proto = synth.proto(rng, B, nm, mh, mw)
-    n = np.array([9, 5], np.int32)
+    n = np.array([200, 150] if many else [9, 5], np.int32)
     det = np.zeros((B, max_det, 6 + nm), F32)
     for b in range(B):
         x1 = rng.random(n[b]) * w0 * 0.6
