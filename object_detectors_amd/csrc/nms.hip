@@ -16,7 +16,7 @@
 //                     wave ballots, one wave resolves the chunk serially with readlane.  Stops
 //                     after max_det keeps (later candidates cannot change earlier keeps).
 //  finalize_boxes_kernel  one workgroup per image: scale/clip boxes in place, per-class threshold, ranks.
-//  finalize_slots_kernel  one workgroup: scan over images -> dense global mask slots and their inverse map.
+//  finalize_slots_kernel  one workgroup per image: prefix of the keep counts -> dense global mask slots and their inverse map.
 #include <cmath>
 
 #include "common.h"
@@ -199,6 +199,7 @@ struct SortNmsParams {
   int *out_count;
   int *out_anchor;
   int lds_keys;  // capacity (keys) of the LDS sort buffer
+  int lbox_off;  // byte offset of the LDS box buffer (lds_keys float4)
 };
 
 __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams S) {
@@ -214,6 +215,8 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
   uint64_t *pairmask = reinterpret_cast<uint64_t *>(kpos + md);
   int *supp = reinterpret_cast<int *>(pairmask + 64);
   int *sK = supp + 64;
+  // sorted class-offset boxes stay in LDS when the candidates fit the LDS sort buffer (no global round trip per chunk)
+  float4 *lbox = reinterpret_cast<float4 *>(smem + S.lbox_off);
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -249,7 +252,8 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
     const float cx = pb[anchor], cy = pb[(size_t)A + anchor], w = pb[(size_t)2 * A + anchor], h = pb[(size_t)3 * A + anchor];
     const float hw = w / 2.0f, hh = h / 2.0f;
     const float c = S.agnostic ? 0.0f : (float)S.cls_of[(size_t)b * A + anchor] * S.max_wh;
-    sbox[i] = make_float4((cx - hw) + c, (cy - hh) + c, (cx + hw) + c, (cy + hh) + c);
+    const float4 bx = make_float4((cx - hw) + c, (cy - hh) + c, (cx + hw) + c, (cy + hh) + c);
+    if (in_lds) lbox[i] = bx; else sbox[i] = bx;
   }
   if (tid < 64) supp[tid] = 0;
   if (tid == 0) *sK = 0;
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
   for (int base = 0; base < n_eff && K < S.max_det; base += 64) {
     const int m = min(64, n_eff - base);
     float4 cb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < m) cb = sbox[base + lane];
+    if (lane < m) cb = in_lds ? lbox[base + lane] : sbox[base + lane];
     const float carea = (cb.z - cb.x) * (cb.w - cb.y);
 
     // A: chunk vs kept boxes, kept index strided over the 16 waves
@@ -401,46 +405,30 @@ __global__ __launch_bounds__(1024) void finalize_boxes_kernel(FinalizeParams F) 
   if (i == 0) F.keep_count[b] = total;
 }
 
-// one workgroup: exclusive scan of keep_count over the images, then global slots and the slot -> (b,i) map
-__global__ __launch_bounds__(1024) void finalize_slots_kernel(FinalizeParams F) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int *m_base = reinterpret_cast<int *>(smem);  // batch
-  int *wtot = m_base + F.batch;                 // one per (round, wave), <= 128 + 1
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rounds = (F.batch + 1023) / 1024;
-  for (int r = 0; r < rounds; ++r) {
-    const int b = r * 1024 + tid;
-    const int v = b < F.batch ? F.keep_count[b] : 0;
-    int incl = v;
+// grid = batch: image b sums keep_count[0..b) itself (batch <= 8192 ints, L2-resident), then turns its ranks into
+// global slots and fills the slot -> (b,i) map.  One launch of `batch` small blocks instead of one block walking
+// batch*max_det entries serially.
+__global__ __launch_bounds__(256) void finalize_slots_kernel(FinalizeParams F) {
+  __shared__ int wsum[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int part = 0;
+  for (int j = tid; j < b; j += 256) part += F.keep_count[j];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(incl, d);
-      if (lane >= d) incl += t;
-    }
-    if (b < F.batch) m_base[b] = incl - v;  // exclusive inside the wave
-    if (lane == 63) wtot[r * 16 + wave] = incl;
-  }
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
+  if (lane == 0) wsum[wave] = part;
   __syncthreads();
-  if (tid == 0) {
-    int s = 0;
-    for (int w = 0; w < rounds * 16; ++w) { const int t = wtot[w]; wtot[w] = s; s += t; }
-    wtot[rounds * 16] = s;
+  const int base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (tid == 0 && F.slot_base) {
+    F.slot_base[b] = base;
+    if (b == F.batch - 1) F.slot_base[F.batch] = base + F.keep_count[b];
   }
-  __syncthreads();
-  for (int b = tid; b < F.batch; b += 1024) {
-    const int base = m_base[b] + wtot[b >> 6];
-    m_base[b] = base;
-    if (F.slot_base) F.slot_base[b] = base;
-  }
-  if (tid == 0 && F.slot_base) F.slot_base[F.batch] = wtot[rounds * 16];
-  __syncthreads();
   if (F.mask_slot) {
-    for (int e = tid; e < F.batch * F.max_det; e += 1024) {
+    for (int i = tid; i < F.max_det; i += 256) {
+      const int e = b * F.max_det + i;
       const int r = F.mask_slot[e];
       if (r >= 0) {
-        const int slot = m_base[e / F.max_det] + r;
-        F.mask_slot[e] = slot;
-        if (F.slot_map) F.slot_map[slot] = e;
+        F.mask_slot[e] = base + r;
+        if (F.slot_map) F.slot_map[base + r] = e;
       }
     }
   }
@@ -499,7 +487,9 @@ int lmi_nms_v8(const float *pred, int batch, int nc, int nm, int anchors, float 
   S.max_det = max_det; S.max_nms = max_nms; S.max_wh = max_wh; S.keys = keys; S.P = L.P; S.cls_of = cls_of;
   S.sbox = sbox; S.cand_count = cand_count; S.out_det = out_det; S.out_count = out_count; S.out_anchor = out_anchor;
   S.lds_keys = L.P < kSortLdsCap ? L.P : kSortLdsCap;
-  const size_t lds = (size_t)S.lds_keys * 8 + 4 * 6 * (size_t)((max_det + 1) & ~1) + 64 * 8 + 64 * 4 + 16;
+  const size_t lds_small = (size_t)S.lds_keys * 8 + 4 * 6 * (size_t)((max_det + 1) & ~1) + 64 * 8 + 64 * 4 + 16;
+  S.lbox_off = (int)((lds_small + 15) & ~(size_t)15);
+  const size_t lds = (size_t)S.lbox_off + (size_t)S.lds_keys * 16;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_suppress), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(nms_sort_suppress, dim3(batch), dim3(kSortThreads), lds, s, S);
   return lmi_check_launch("nms_sort_suppress");
@@ -526,8 +516,7 @@ int lmi_finalize_detections(float *det, const int32_t *count, int batch, int max
   int rc = lmi_check_launch("finalize_boxes_kernel");
   if (rc) return rc;
   if (mask_slot == nullptr && slot_base == nullptr) return LMI_OK;
-  const size_t lds = sizeof(int) * ((size_t)batch + 16 * ((batch + 1023) / 1024) + 1) + 16;
-  hipLaunchKernelGGL(finalize_slots_kernel, dim3(1), dim3(1024), lds, s, F);
+  hipLaunchKernelGGL(finalize_slots_kernel, dim3(batch), dim3(256), 0, s, F);
   return lmi_check_launch("finalize_slots_kernel");
 }
 
