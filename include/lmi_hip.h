@@ -47,6 +47,7 @@ enum lmi_resize_mode { LMI_RESIZE_CV2_LINEAR = 0 };
 
 #define LMI_MAX_DET_CAP 1024   /* largest max_det lmi_nms_v8 accepts */
 #define LMI_MAX_MASK_DIM 32    /* number of prototype channels (nm) the mask kernels are built for */
+#define LMI_MAX_POINT_OPS 16   /* longest operator list lmi_revert_points_f32 accepts */
 
 int lmi_version(void);
 const char *lmi_status_string(int status);
@@ -168,7 +169,8 @@ int lmi_finalize_detections(float *det, const int32_t *count, int batch, int max
 /* ------------------------------------------------------------------------------------------
  * Masks -- replaces `ops.process_mask_native(proto[i], pred[:, 6:], pred[:, :4],
  * orig_img.shape[:2])` + `masks[M]` (object_detectors/yolov8_lmi/model.py:235-236; in-tree
- * YOLOv5 analogue yolov5_trt.py:373-415): logits = coef @ proto on fp32 MFMA, then fused
+ * YOLOv5 analogue yolov5_trt.py:373-415): logits = coef @ proto as a k-ordered fp32 fma chain
+ * (only the rows under each survivor's box; dense fp32 MFMA tiles for odd prototype widths), then fused
  * letterbox-pad crop -> bilinear upsample (align_corners=False) to the ORIGINAL frame -> crop to
  * the rescaled box -> `> 0`, written once as uint8 (or fp32 0./1.).
  *   proto      [device] fp32 (batch, 32, mh, mw)
@@ -179,7 +181,7 @@ int lmi_finalize_detections(float *det, const int32_t *count, int batch, int max
  *              their number is written to overflow[0] ([device] int32, may be NULL)
  *   workspace  [device] >= lmi_mask_workspace_bytes(capacity_masks, mh, mw), 256-byte aligned
  * Only uniform originals (every image H0 x W0) are supported by this entry.
- * lmi_process_mask = lmi_mask_logits (the MFMA GEMM into `workspace`) followed by
+ * lmi_process_mask = lmi_mask_logits (the coefficient x prototype product into `workspace`) followed by
  * lmi_mask_upsample (crop + bilinear + box crop + threshold from `workspace`); the two halves are
  * exported so a caller can time or schedule them separately.
  */
@@ -197,6 +199,43 @@ int lmi_process_mask(const float *proto, int batch, int nm, int mh, int mw, cons
                      const int32_t *slot_base, int h0, int w0, void *out_masks, int out_dtype,
                      int64_t capacity_masks, int32_t *overflow, void *workspace,
                      int64_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Operator-list revert on the device, batched -- replaces the per-mask and
+ * per-segment Python loops around `pipeline_utils.revert_to_origin`
+ * (lmi_utils/gadget_utils/pipeline_utils.py:422-476) and `pipeline_utils.revert_masks_to_origin`
+ * (:374-418 -> resize_image :23-68, fit_im_to_size :72-142) in `Yolov8.predict`
+ * (object_detectors/yolov8_lmi/model.py:308-318).
+ *
+ * lmi_revert_points_f32: pts/out [device] fp32 (n_pairs, 2) (x, y) pairs -- an (N,4) box array is
+ *   2N pairs.  `ops` [host] lists the steps in RECORDED order; they are undone last to first in
+ *   fp32 (IEEE division), then rounded half-to-even and clamped at 0, exactly `revert_to_origin`:
+ *     {'resize':[tw,th,ow,oh]} -> {LMI_POINT_DIV, (float)(tw/ow), (float)(th/oh)}   (ratio in double first)
+ *     {'stretch':[sx,sy]}      -> {LMI_POINT_DIV, sx, sy}
+ *     {'pad':[L,R,T,B]}        -> {LMI_POINT_SUB, L, T}
+ *     {'flip':[lr,ud,w,h]}     -> {LMI_POINT_FLIP_X | _Y | _XY, w, h}
+ *   pts == out is allowed.
+ * lmi_revert_masks_stage: one fused step of `revert_mask_to_origin` on a stack of m planes
+ *   (m, src_h, src_w) of dtype LMI_F32 or LMI_U8:
+ *     1. fit_h/fit_w > 0: centred crop / zero pad to (fit_h, fit_w)  (fit_im_to_size; 0 = keep)
+ *     2. resize_h/resize_w > 0: bilinear resize, align_corners=False (resize_image; integer masks are
+ *        interpolated in fp32 and truncated; 0 = none)
+ *     3. flip_lr / flip_ud
+ *   dst [device] (m, out_h, out_w), out = resize size if given, else the fit size; dst != src.
+ *   A reverted 'pad' operator [L,R,T,B] is step 1 with (fit_w, fit_h) = (w-L-R, h-T-B); a reverted
+ *   'resize' [tw,th,ow,oh] is step 2 with (ow, oh).  Longer lists are chains of stages (see
+ *   object_detectors_amd/hip_ops.py:revert_masks).
+ */
+enum lmi_point_kind { LMI_POINT_DIV = 1, LMI_POINT_SUB = 2, LMI_POINT_FLIP_X = 3, LMI_POINT_FLIP_Y = 4, LMI_POINT_FLIP_XY = 5 };
+typedef struct lmi_point_op {
+  int32_t kind; /* enum lmi_point_kind */
+  float x, y;
+} lmi_point_op;
+int lmi_revert_points_f32(const float *pts, int64_t n_pairs, const lmi_point_op *ops, int n_ops,
+                          float *out, void *stream);
+int lmi_revert_masks_stage(const void *src, int dtype, int64_t m, int src_h, int src_w, int fit_h,
+                           int fit_w, int resize_h, int resize_w, int flip_lr, int flip_ud,
+                           void *dst, void *stream);
 
 #ifdef __cplusplus
 }

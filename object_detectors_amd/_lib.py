@@ -26,6 +26,14 @@ class lmi_frame(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class lmi_point_op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("x", C.c_float), ("y", C.c_float)]
+
+
+LMI_POINT_DIV, LMI_POINT_SUB, LMI_POINT_FLIP_X, LMI_POINT_FLIP_Y, LMI_POINT_FLIP_XY = 1, 2, 3, 4, 5
+LMI_MAX_POINT_OPS = 16
+
+
 # name -> (restype, argtypes); must list every symbol include/lmi_hip.h declares
 SIGNATURES = {
     "lmi_version": (C.c_int, []),
@@ -54,6 +62,9 @@ SIGNATURES = {
     "lmi_process_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p,
                                    C.c_void_p, C.c_int64, C.c_void_p]),
+    "lmi_revert_points_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "lmi_revert_masks_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

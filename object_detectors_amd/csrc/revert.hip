@@ -1,0 +1,211 @@
+// Operator-list revert on the device, batched.
+//
+// Replaces the per-mask / per-segment Python loops of
+//   pipeline_utils.revert_to_origin          lmi_utils/gadget_utils/pipeline_utils.py:422-476
+//   pipeline_utils.revert_mask(s)_to_origin  lmi_utils/gadget_utils/pipeline_utils.py:374-418
+//     -> resize_image :23-68 (F.interpolate bilinear, align_corners=False; integer masks go through fp32 and are
+//        truncated on the way back), fit_im_to_size :72-142 (centred crop / zero pad), torch.flip
+// as called from Yolov8.predict (object_detectors/yolov8_lmi/model.py:308-318).  Semantics: oracle/geometry.py.
+//
+// Kernels
+//  revert_points_kernel      one lane per (x, y) pair; the operator list (<= 16 steps, by value) applied last to
+//                            first in fp32 with IEEE division, then rint (half to even) and clamp at 0.
+//  revert_masks_kernel<T>    one stage = [centred crop / zero pad] -> [bilinear resize] -> [flip], fused: the crop
+//                            and pad are index arithmetic on the resize taps, the flip mirrors the store address.
+//                            16 bytes per lane per store; write-bound when it enlarges (640x360 -> 1920x1080).
+#include "common.h"
+
+namespace {
+
+struct PointOps {
+  int n;
+  int kind[LMI_MAX_POINT_OPS];
+  float x[LMI_MAX_POINT_OPS], y[LMI_MAX_POINT_OPS];
+};
+
+__global__ __launch_bounds__(256) void revert_points_kernel(const float *pts, float *out, long long npairs, PointOps P) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npairs) return;
+  float x = pts[2 * i], y = pts[2 * i + 1];
+  for (int k = P.n - 1; k >= 0; --k) {  // operations are undone last to first
+    const float a = P.x[k], b = P.y[k];
+    switch (P.kind[k]) {
+      case LMI_POINT_DIV: x = x / a; y = y / b; break;
+      case LMI_POINT_SUB: x = x - a; y = y - b; break;
+      case LMI_POINT_FLIP_X: x = a - x; break;
+      case LMI_POINT_FLIP_Y: y = b - y; break;
+      case LMI_POINT_FLIP_XY: x = a - x; y = b - y; break;
+      default: break;
+    }
+  }
+  out[2 * i] = fmaxf(rintf(x), 0.0f);
+  out[2 * i + 1] = fmaxf(rintf(y), 0.0f);
+}
+
+struct MaskStage {
+  const void *src;
+  void *dst;
+  long long m;
+  int sh, sw;      // source planes
+  int oy, ox;      // virtual image V[y][x] = src[y + oy][x + ox], zero outside the source
+  int vh, vw;      // size of V (after the centred crop / pad)
+  int dh, dw;      // output planes
+  int resize;      // 1: bilinear V -> (dh, dw); 0: dh == vh, dw == vw, copy
+  int flip_lr, flip_ud;
+};
+
+// aten upsample_bilinear2d, align_corners=False, with the contractions of torch's x86 build (oracle/geometry.py:
+// only the fused forms reproduce F.interpolate bit for bit): the source coordinate is ONE fused multiply-add and
+// each pair of taps is combined as fma(a, wa, b*wb).
+__device__ __forceinline__ void bilinear_src(float scale, int d, int in_n, int &i0, int &i1, float &l0, float &l1) {
+  float s = fmaf(scale, (float)d + 0.5f, -0.5f);
+  s = fmaxf(s, 0.0f);
+  i0 = min((int)s, in_n - 1);
+  i1 = i0 + ((i0 < in_n - 1) ? 1 : 0);
+  l1 = fminf(fmaxf(s - (float)i0, 0.0f), 1.0f);
+  l0 = 1.0f - l1;
+}
+
+template <typename T>
+struct Px;
+template <>
+struct Px<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ float load(const float *p) { return *p; }
+  static __device__ __forceinline__ float from_interp(float v) { return v; }
+  static __device__ __forceinline__ void store(float *p, const float (&v)[4]) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 o = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(o, reinterpret_cast<f4 *>(p));
+  }
+};
+template <>
+struct Px<uint8_t> {
+  static constexpr int N = 16;
+  static __device__ __forceinline__ float load(const uint8_t *p) { return (float)*p; }
+  // `.to(uint8)` of the interpolated fp32 value: truncation toward zero (values stay inside 0..255)
+  static __device__ __forceinline__ uint8_t from_interp(float v) { return (uint8_t)(int)v; }
+  static __device__ __forceinline__ void store(uint8_t *p, const uint8_t (&v)[16]) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    uint32_t w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = v[4 * q] | (v[4 * q + 1] << 8) | (v[4 * q + 2] << 16) | ((uint32_t)v[4 * q + 3] << 24);
+    u4 o = {w[0], w[1], w[2], w[3]};
+    __builtin_nontemporal_store(o, reinterpret_cast<u4 *>(p));
+  }
+};
+
+// grid: x = chunk columns (N pixels each) in groups of 64 lanes, y = output rows in groups of 4, z = mask
+template <typename T>
+__global__ __launch_bounds__(256) void revert_masks_kernel(MaskStage S) {
+  constexpr int N = Px<T>::N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int y = blockIdx.y * 4 + wave;  // output row before the flip
+  const int x0 = (blockIdx.x * 64 + lane) * N;
+  if (y >= S.dh || x0 >= S.dw) return;
+  const long long mi = blockIdx.z;
+  const T *src = reinterpret_cast<const T *>(S.src) + (size_t)mi * S.sh * S.sw;
+  T *dst = reinterpret_cast<T *>(S.dst) + (size_t)mi * S.dh * S.dw;
+
+  auto tap = [&](int vy, int vx) -> float {  // V[vy][vx] as fp32
+    const int sy = vy + S.oy, sx = vx + S.ox;
+    if (sy < 0 || sy >= S.sh || sx < 0 || sx >= S.sw) return 0.0f;
+    return Px<T>::load(src + (size_t)sy * S.sw + sx);
+  };
+
+  T v[N];
+  if (S.resize) {
+    const float scale_h = (float)S.vh / (float)S.dh, scale_w = (float)S.vw / (float)S.dw;
+    int iy0, iy1; float ly0, ly1;
+    bilinear_src(scale_h, y, S.vh, iy0, iy1, ly0, ly1);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int x = x0 + k;
+      int ix0, ix1; float lx0, lx1;
+      bilinear_src(scale_w, min(x, S.dw - 1), S.vw, ix0, ix1, lx0, lx1);
+      const float t0 = fmaf(tap(iy0, ix0), lx0, tap(iy0, ix1) * lx1);
+      const float t1 = fmaf(tap(iy1, ix0), lx0, tap(iy1, ix1) * lx1);
+      v[k] = Px<T>::from_interp(fmaf(t0, ly0, t1 * ly1));
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int sy = y + S.oy, sx = x0 + k + S.ox;
+      const bool in = sy >= 0 && sy < S.sh && sx >= 0 && sx < S.sw && x0 + k < S.dw;
+      v[k] = in ? src[(size_t)sy * S.sw + sx] : (T)0;
+    }
+  }
+
+  const int yo = S.flip_ud ? S.dh - 1 - y : y;
+  T *row = dst + (size_t)yo * S.dw;
+  const bool full = x0 + N <= S.dw;
+  if (!S.flip_lr) {
+    if (full && ((reinterpret_cast<uintptr_t>(row + x0) & 15) == 0)) {
+      Px<T>::store(row + x0, v);
+    } else {
+      for (int k = 0; k < N && x0 + k < S.dw; ++k) row[x0 + k] = v[k];
+    }
+  } else {
+    const int xe = S.dw - x0 - N;  // mirrored chunk starts here
+    if (full && ((reinterpret_cast<uintptr_t>(row + xe) & 15) == 0)) {
+      T r[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) r[k] = v[N - 1 - k];
+      Px<T>::store(row + xe, r);
+    } else {
+      for (int k = 0; k < N && x0 + k < S.dw; ++k) row[S.dw - 1 - (x0 + k)] = v[k];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int lmi_revert_points_f32(const float *pts, int64_t n_pairs, const lmi_point_op *ops, int n_ops, float *out, void *stream) {
+  LMI_REQUIRE(n_pairs >= 0 && n_ops >= 0, LMI_ERR_BAD_ARG, "lmi_revert_points_f32: negative count");
+  LMI_REQUIRE(n_ops <= LMI_MAX_POINT_OPS, LMI_ERR_LIMIT, "lmi_revert_points_f32: %d operations > %d", n_ops, LMI_MAX_POINT_OPS);
+  if (n_pairs == 0) return LMI_OK;
+  LMI_REQUIRE(pts && out && (ops || n_ops == 0), LMI_ERR_BAD_ARG, "lmi_revert_points_f32: NULL pointer");
+  LMI_REQUIRE(n_pairs <= (int64_t)0x7fffffff * 128, LMI_ERR_LIMIT, "lmi_revert_points_f32: too many points");
+  PointOps P;
+  P.n = n_ops;
+  for (int k = 0; k < n_ops; ++k) {
+    LMI_REQUIRE(ops[k].kind >= LMI_POINT_DIV && ops[k].kind <= LMI_POINT_FLIP_XY, LMI_ERR_BAD_ARG,
+                "lmi_revert_points_f32: unsupported operation kind %d", ops[k].kind);
+    P.kind[k] = ops[k].kind; P.x[k] = ops[k].x; P.y[k] = ops[k].y;
+  }
+  const unsigned grid = (unsigned)((n_pairs + 255) / 256);
+  hipLaunchKernelGGL(revert_points_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts, out, (long long)n_pairs, P);
+  return lmi_check_launch("revert_points_kernel");
+}
+
+int lmi_revert_masks_stage(const void *src, int dtype, int64_t m, int src_h, int src_w, int fit_h, int fit_w, int resize_h,
+                           int resize_w, int flip_lr, int flip_ud, void *dst, void *stream) {
+  LMI_REQUIRE(dtype == LMI_F32 || dtype == LMI_U8, LMI_ERR_BAD_ARG, "lmi_revert_masks_stage: dtype must be LMI_F32 or LMI_U8");
+  LMI_REQUIRE(m >= 0 && m <= 65535, LMI_ERR_LIMIT, "lmi_revert_masks_stage: %lld masks not in 0..65535", (long long)m);
+  LMI_REQUIRE(src_h > 0 && src_w > 0, LMI_ERR_BAD_ARG, "lmi_revert_masks_stage: bad source size %dx%d", src_h, src_w);
+  MaskStage S;
+  S.src = src; S.dst = dst; S.m = m; S.sh = src_h; S.sw = src_w;
+  // fit_im_to_size: centred; when growing pad_before = (want - have) // 2, when shrinking crop_before = (have - want) // 2
+  S.vh = fit_h > 0 ? fit_h : src_h;
+  S.vw = fit_w > 0 ? fit_w : src_w;
+  S.oy = S.vh >= src_h ? -((S.vh - src_h) / 2) : (src_h - S.vh) / 2;
+  S.ox = S.vw >= src_w ? -((S.vw - src_w) / 2) : (src_w - S.vw) / 2;
+  S.resize = (resize_h > 0 || resize_w > 0) ? 1 : 0;
+  LMI_REQUIRE(!S.resize || (resize_h > 0 && resize_w > 0), LMI_ERR_BAD_ARG, "lmi_revert_masks_stage: resize needs both sides");
+  S.dh = S.resize ? resize_h : S.vh;
+  S.dw = S.resize ? resize_w : S.vw;
+  S.flip_lr = flip_lr ? 1 : 0; S.flip_ud = flip_ud ? 1 : 0;
+  if (m == 0) return LMI_OK;
+  LMI_REQUIRE(src && dst, LMI_ERR_BAD_ARG, "lmi_revert_masks_stage: NULL pointer");
+  const int n = dtype == LMI_F32 ? 4 : 16;
+  dim3 grid(((S.dw + n - 1) / n + 63) / 64, (S.dh + 3) / 4, (unsigned)m);
+  LMI_REQUIRE(grid.y <= 65535, LMI_ERR_LIMIT, "lmi_revert_masks_stage: output height %d too large", S.dh);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == LMI_F32) hipLaunchKernelGGL(revert_masks_kernel<float>, grid, dim3(256), 0, s, S);
+  else hipLaunchKernelGGL(revert_masks_kernel<uint8_t>, grid, dim3(256), 0, s, S);
+  return lmi_check_launch("revert_masks_kernel");
+}
+
+}  // extern "C"

@@ -139,10 +139,19 @@ def revert_mask_to_origin(mask, operations: list):
     return mask
 
 
+def _hip_ops():
+    from object_detectors_amd import hip_ops  # raises if liblmi_hip.so is missing: no silent fallback on a GPU box
+    return hip_ops
+
+
 def revert_masks_to_origin(masks, operations: list):
-    """Undo the operator list on a stack / list of masks; the container kind follows the input."""
+    """Undo the operator list on a stack / list of masks; the container kind follows the input.
+    A stack of fp32 / uint8 masks that lives on the GPU is reverted there, all masks per launch
+    (object_detectors_amd/csrc/revert.hip); host arrays keep the reference's per-mask torch-CPU route."""
     if len(masks) == 0:
         return []
+    if isinstance(masks, torch.Tensor) and masks.is_cuda and masks.ndim == 3 and masks.dtype in (torch.float32, torch.uint8):
+        return _hip_ops().revert_masks(masks, operations)
     out = [revert_mask_to_origin(m, operations) for m in masks]
     if isinstance(masks[0], torch.Tensor):
         return torch.stack(out)
@@ -156,6 +165,8 @@ def revert_to_origin(pts, operations: list):
     t, kind = _to_tensor(pts)
     if t.ndim != 2 or t.shape[1] not in (2, 4):
         raise Exception(f'pts should be Nx2 or Nx4, got shape: {t.shape}')
+    if kind == "tensor" and t.is_cuda and t.dtype == torch.float32:
+        return _hip_ops().revert_points(t, operations)  # one launch, same fp32 arithmetic (csrc/revert.hip)
     reps = t.shape[1] // 2
 
     def per_xy(vals):

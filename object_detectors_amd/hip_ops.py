@@ -245,3 +245,106 @@ def process_mask(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.Tensor,
                                    slot_base.data_ptr(), h0, w0, out.data_ptr(), ldt, capacity, overflow.data_ptr(), _stream()))
         split_events[1].record()
     return out, overflow
+
+
+def point_ops(operations: Sequence[dict]):
+    """Operator list -> (ctypes array of lmi_point_op, n) for lmi_revert_points_f32.  The divisor of a 'resize'
+    is the Python-float ratio rounded to fp32, as `torch.tensor([tw/orig_w, th/orig_h])` does
+    (lmi_utils/gadget_utils/pipeline_utils.py:447)."""
+    rows = []
+    for op in operations:
+        if 'resize' in op:
+            tw, th, ow, oh = op['resize']
+            rows.append((_lib.LMI_POINT_DIV, tw / ow, th / oh))
+        elif 'pad' in op:
+            rows.append((_lib.LMI_POINT_SUB, op['pad'][0], op['pad'][2]))
+        elif 'stretch' in op:
+            rows.append((_lib.LMI_POINT_DIV, op['stretch'][0], op['stretch'][1]))
+        elif 'flip' in op:
+            lr, ud, im_w, im_h = op['flip']
+            if lr or ud:
+                kind = _lib.LMI_POINT_FLIP_XY if (lr and ud) else (_lib.LMI_POINT_FLIP_X if lr else _lib.LMI_POINT_FLIP_Y)
+                rows.append((kind, im_w, im_h))
+        else:
+            raise Exception(f'unsupported operation: {op}')
+    arr = (_lib.lmi_point_op * max(len(rows), 1))()
+    for i, (k, x, y) in enumerate(rows):
+        arr[i].kind, arr[i].x, arr[i].y = k, float(np.float32(x)), float(np.float32(y))
+    return arr, len(rows)
+
+
+def revert_points(pts: torch.Tensor, operations: Sequence[dict]) -> torch.Tensor:
+    """`pipeline_utils.revert_to_origin` for an fp32 (N,2) / (N,4) tensor on the device: one launch for the whole
+    array whatever the length of the operator list.  Returns a new tensor."""
+    _need_cuda(pts, "pts")
+    if pts.ndim != 2 or pts.shape[1] not in (2, 4):
+        raise Exception(f'pts should be Nx2 or Nx4, got shape: {pts.shape}')
+    if pts.dtype != torch.float32:
+        raise TypeError("revert_points handles fp32 points (what the detector emits)")
+    src = pts.contiguous()
+    out = torch.empty_like(src)
+    arr, n = point_ops(operations)
+    check(_L.lmi_revert_points_f32(src.data_ptr(), src.numel() // 2, C.cast(arr, C.c_void_p), n, out.data_ptr(), _stream()))
+    return out
+
+
+def mask_stages(h: int, w: int, operations: Sequence[dict]):
+    """Split the reverted operator list into fused stages [(fit_h, fit_w, resize_h, resize_w, lr, ud, out_h, out_w)]:
+    every stage is at most one centred crop/pad, then one resize, then one flip, in that order."""
+    stages, cur = [], None
+
+    def flush():
+        nonlocal cur
+        if cur is not None:
+            stages.append(cur)
+            cur = None
+
+    def need(level):  # 1 fit, 2 resize, 3 flip: a stage applies them in ascending order, once each
+        nonlocal cur
+        if cur is None or cur["level"] >= level:
+            flush()
+            cur = {"level": 0, "fit": (0, 0), "resize": (0, 0), "lr": False, "ud": False}
+        cur["level"] = level
+
+    for op in reversed(list(operations)):
+        if 'resize' in op:
+            _, _, ow, oh = op['resize']
+            need(2)
+            cur["resize"] = (int(oh), int(ow))
+            h, w = int(oh), int(ow)
+        if 'pad' in op:
+            left, right, top, bottom = op['pad']
+            nh, nw = h - top - bottom, w - left - right
+            if nh <= 0 or nw <= 0:
+                raise ValueError(f"pad {op['pad']} leaves no pixels of a {h}x{w} mask")
+            need(1)
+            cur["fit"] = (int(nh), int(nw))
+            h, w = int(nh), int(nw)
+        if 'flip' in op:
+            lr, ud = bool(op['flip'][0]), bool(op['flip'][1])
+            if lr or ud:
+                need(3)
+                cur["lr"], cur["ud"] = lr, ud
+        if cur is not None:
+            cur["out"] = (h, w)
+    flush()
+    return [(s["fit"][0], s["fit"][1], s["resize"][0], s["resize"][1], s["lr"], s["ud"], s["out"][0], s["out"][1]) for s in stages]
+
+
+def revert_masks(masks: torch.Tensor, operations: Sequence[dict]) -> torch.Tensor:
+    """`pipeline_utils.revert_masks_to_origin` for a stack (m,H,W) of fp32 or uint8 masks on the device: one launch
+    per fused stage for ALL masks (the reference loops over masks in Python, three torch ops each)."""
+    _need_cuda(masks, "masks")
+    if masks.ndim != 3:
+        raise ValueError(f"masks must be (m,H,W), got {tuple(masks.shape)}")
+    ldt = {torch.uint8: LMI_U8, torch.float32: LMI_F32}.get(masks.dtype)
+    if ldt is None:
+        raise TypeError("revert_masks handles fp32 and uint8 masks")
+    cur = masks.contiguous()
+    m = cur.shape[0]
+    for fit_h, fit_w, rs_h, rs_w, lr, ud, oh, ow in mask_stages(cur.shape[1], cur.shape[2], operations):
+        out = torch.empty((m, oh, ow), dtype=cur.dtype, device=cur.device)
+        check(_L.lmi_revert_masks_stage(cur.data_ptr(), ldt, m, cur.shape[1], cur.shape[2], fit_h, fit_w, rs_h, rs_w,
+                                        1 if lr else 0, 1 if ud else 0, out.data_ptr(), _stream()))
+        cur = out
+    return cur

@@ -168,7 +168,8 @@ class Yolov8Core:
 
     # ---- postprocess (model.py:178-252) ----------------------------------------------------------
     @torch.inference_mode()
-    def postprocess(self, preds, img, orig_imgs, conf: Union[float, dict], iou=0.45, agnostic=False, max_det=300, return_segments=True):
+    def postprocess(self, preds, img, orig_imgs, conf: Union[float, dict], iou=0.45, agnostic=False, max_det=300, return_segments=True,
+                    _masks_on_device=False):
         if isinstance(preds, (list, tuple)):
             predict_mask = preds[0].shape[1] != 4 + len(self.model.names)
         elif isinstance(preds, torch.Tensor):
@@ -217,7 +218,7 @@ class Yolov8Core:
         count_h = count.cpu().numpy()
         keep_h = keep.cpu().numpy().astype(bool)
         det_h = det[:, :, :6].cpu().numpy()
-        return self._assemble(det, det_h, count_h, keep_h, masks_by_image, orig_imgs, predict_mask, return_segments)
+        return self._assemble(det, det_h, count_h, keep_h, masks_by_image, orig_imgs, predict_mask, return_segments, _masks_on_device)
 
     def _masks_one_image(self, ops, proto1, det1, keep1, shape):
         k = keep1[0].to(torch.int32)
@@ -231,8 +232,9 @@ class Yolov8Core:
         masks, _ = ops.process_mask(proto1, det1, slot_map, slot_base, shape, m, self.mask_dtype)
         return masks
 
-    def _assemble(self, det, det_h, count_h, keep_h, masks_by_image, orig_imgs, predict_mask, return_segments):
-        """Result dict exactly as model.py:214-252 builds it (images with no NMS survivor add no entry)."""
+    def _assemble(self, det, det_h, count_h, keep_h, masks_by_image, orig_imgs, predict_mask, return_segments, masks_on_device=False):
+        """Result dict exactly as model.py:214-252 builds it (images with no NMS survivor add no entry).
+        masks_on_device: leave the masks of numpy-input images on the GPU (predict reverts them there first)."""
         results = collections.defaultdict(list)
         names = self.model.names
         for i in range(len(count_h)):
@@ -247,7 +249,7 @@ class Yolov8Core:
                 masks = masks_by_image[i]
                 if masks is None:
                     masks = torch.zeros((0,) + tuple(orig_img.shape[:2]), dtype=self.mask_dtype, device=self.device)
-                results['masks'].append(masks if return_tensor else masks.cpu().numpy())
+                results['masks'].append(masks if (return_tensor or masks_on_device) else masks.cpu().numpy())
                 if return_segments:
                     segments = masks2segments(masks)
                     if return_tensor:
@@ -275,16 +277,27 @@ class Yolov8Core:
         pred = self.forward(im)
         time_info['proc'] = time.time() - t0
         t0 = time.time()
-        results = self.postprocess(pred, im, image, configs, iou, agnostic, max_det, return_segments)
+        # masks of a numpy image stay on the GPU until the operator list is undone there (one launch per stage for
+        # all masks instead of the reference's per-mask torch-CPU loop, pipeline_utils.py:408-418)
+        on_device = bool(operators) and not isinstance(image, torch.Tensor)
+        results = self.postprocess(pred, im, image, configs, iou, agnostic, max_det, return_segments, _masks_on_device=on_device)
         results_dict = collections.defaultdict(list)
         if not len(results['boxes']):
             time_info['postproc'] = time.time() - t0
             return results_dict, time_info
         boxes, scores, classes = results['boxes'][0], results['scores'][0], results['classes'][0]
         if len(results['masks']):
-            results_dict['masks'] = pipeline_utils.revert_masks_to_origin(results['masks'][0], operators)
+            masks = pipeline_utils.revert_masks_to_origin(results['masks'][0], operators)
+            if on_device and isinstance(masks, torch.Tensor):
+                masks = masks.cpu().numpy()
+            results_dict['masks'] = masks
         if return_segments and len(results['segments']):
-            results_dict['segments'] = [pipeline_utils.revert_to_origin(seg, operators) for seg in results['segments'][0]]
+            segs = results['segments'][0]
+            if len(segs) and all(isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 for x in segs):
+                flat = pipeline_utils.revert_to_origin(torch.cat(segs), operators)   # every contour in one launch
+                results_dict['segments'] = list(torch.split(flat, [len(x) for x in segs]))
+            else:
+                results_dict['segments'] = [pipeline_utils.revert_to_origin(seg, operators) for seg in segs]
         results_dict['boxes'] = pipeline_utils.revert_to_origin(boxes, operators)
         results_dict['scores'] = scores
         results_dict['classes'] = classes

@@ -135,3 +135,64 @@ def resize_target(h: int, w: int, W=None, H=None):
     elif H is None:
         H = int(h * W / w)
     return W, H
+
+
+# ---------------------------------------------------------------------------------------------
+# Mask revert (lmi_utils/gadget_utils/pipeline_utils.py:374-418 -> resize_image :23-68,
+# fit_im_to_size :72-142, torch.flip).  PINNED: tests/golden/revert_masks.npz holds outputs of the
+# reference's revert_masks_to_origin run in the build container (tests/golden/make_golden_revert_masks.py).
+def _fma(a, b, c):
+    """fp32 fused multiply-add: the fp64 product of two fp32 values is exact, so one rounding at the end."""
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(F32)
+
+
+def _bilinear_axis(in_n: int, out_n: int):
+    """aten linear index/weight tables, align_corners=False, fp32.  The x86 build of torch 2.10 contracts
+    `scale * (dst + 0.5) - 0.5` into one fused multiply-add (probed here: only the fused form reproduces
+    F.interpolate bit for bit), unlike oracle/masks.py:bilinear_axis which keeps the two roundings."""
+    scale = F32(in_n) / F32(out_n)
+    d = np.arange(out_n, dtype=F32)
+    src = np.maximum(_fma(scale, d + F32(0.5), F32(-0.5)), F32(0))
+    i0 = np.minimum(src.astype(np.int64), in_n - 1)
+    i1 = i0 + (i0 < in_n - 1)
+    l1 = np.clip((src - i0.astype(F32)).astype(F32), F32(0), F32(1))
+    return i0, i1, (F32(1) - l1).astype(F32), l1
+
+
+def resize_bilinear(im: np.ndarray, W: int, H: int) -> np.ndarray:
+    """resize_image(im, W, H) for an (H,W) plane: fp32 bilinear, horizontal taps first then vertical, each pair
+    combined as fma(a, wa, b*wb) -- the operation order of aten's CPU kernel as built for x86 (bit-exact against
+    F.interpolate for enlargements, see tests/test_oracle_geometry.py; aten's own result for reductions depends
+    on its vectorisation path, so those are compared with a tolerance).  Integer planes are interpolated in fp32
+    and truncated on the cast back."""
+    src = im.astype(F32)
+    y0, y1, wy0, wy1 = _bilinear_axis(src.shape[0], H)
+    x0, x1, wx0, wx1 = _bilinear_axis(src.shape[1], W)
+    wx0, wx1 = np.broadcast_to(wx0, (H, W)), np.broadcast_to(wx1, (H, W))
+    wy0, wy1 = np.broadcast_to(wy0[:, None], (H, W)), np.broadcast_to(wy1[:, None], (H, W))
+    r0 = _fma(src[y0][:, x0], wx0, (src[y0][:, x1] * wx1).astype(F32))
+    r1 = _fma(src[y1][:, x0], wx0, (src[y1][:, x1] * wx1).astype(F32))
+    out = _fma(r0, wy0, (r1 * wy1).astype(F32))
+    return out if np.issubdtype(im.dtype, np.floating) else out.astype(im.dtype)
+
+
+def revert_mask_to_origin(mask: np.ndarray, operations) -> np.ndarray:
+    for op in reversed(list(operations)):
+        if 'resize' in op:
+            _, _, nw, nh = op['resize']
+            mask = resize_bilinear(mask, nw, nh)
+        if 'pad' in op:
+            h, w = mask.shape[:2]
+            pl, pr, pt, pb = op['pad']
+            mask, *_ = fit_im_to_size(mask, w - pl - pr, h - pt - pb)
+        if 'flip' in op:
+            lr, ud = op['flip'][0], op['flip'][1]
+            if lr:
+                mask = mask[:, ::-1]
+            if ud:
+                mask = mask[::-1]
+    return np.ascontiguousarray(mask)
+
+
+def revert_masks_to_origin(masks: np.ndarray, operations) -> np.ndarray:
+    return np.stack([revert_mask_to_origin(m, operations) for m in masks]) if len(masks) else masks

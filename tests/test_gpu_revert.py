@@ -1,0 +1,99 @@
+"""GPU parity for the device-side operator-list revert: lmi_revert_points_f32 and
+lmi_revert_masks_stage against (a) outputs of the reference's own revert_to_origin / revert_masks_to_origin
+(tests/golden/l1_geometry.json, tests/golden/revert_masks.npz) and (b) the numpy oracle on larger seeded inputs.
+Bars: points bit-exact; fp32 masks bit-exact for enlargements (aten's CPU result for reductions depends on its
+vectorisation path: <= 1 level on <= 2 % of the pixels there)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import geometry as OG
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    from object_detectors_amd import hip_ops
+    return hip_ops
+
+
+def test_revert_points_golden_and_random(ops):
+    gold = json.load(open(os.path.join(HERE, "golden", "l1_geometry.json")))
+    n = 0
+    for case in gold["revert"]:
+        if case["kind"] != "f32" or not case["tensor"]:
+            continue
+        pts = torch.tensor(case["pts"], dtype=torch.float32).cuda()
+        got = ops.revert_points(pts, case["ops"]).cpu().numpy()
+        assert np.array_equal(got, np.array(case["out"], F32))
+        n += 1
+    assert n >= 4
+    rng = np.random.default_rng(21)
+    for cols, oplist in [(4, [{"resize": [640, 427, 1333, 889]}, {"pad": [0, 0, 106, 107]}]),
+                         (2, [{"resize": [640, 360, 3840, 2160]}, {"pad": [0, 0, 140, 140]}, {"flip": [True, True, 640, 640]}]),
+                         (4, [{"stretch": [1.3, 0.7]}, {"pad": [-5, -6, 7, 8]}, {"flip": [False, True, 100, 200]}, {"resize": [300, 200, 77, 91]}]),
+                         (2, [])]:
+        p = (rng.random((5000, cols)) * 700 - 30).astype(F32)
+        got = ops.revert_points(torch.from_numpy(p).cuda(), oplist).cpu().numpy()
+        ref = OG.revert_to_origin(p, oplist)
+        assert got.dtype == np.float32 and np.array_equal(got, np.asarray(ref, F32))
+    with pytest.raises(Exception):
+        ops.revert_points(torch.zeros((3, 3), device="cuda"), [])
+    with pytest.raises(Exception):
+        ops.revert_points(torch.zeros((3, 2), device="cuda"), [{"rotate": [1]}])
+
+
+def test_revert_masks_golden(ops):
+    z = np.load(os.path.join(HERE, "golden", "revert_masks.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    for i, c in enumerate(meta["cases"]):
+        src, ref = z[f"in{i}"], z[f"out{i}"]
+        got = ops.revert_masks(torch.from_numpy(src).cuda(), c["ops"]).cpu().numpy()
+        assert got.shape == ref.shape and got.dtype == ref.dtype
+        assert np.array_equal(got, OG.revert_masks_to_origin(src, c["ops"]))     # the oracle, bit for bit
+        shrinks = any("resize" in op and (op["resize"][2] < op["resize"][0] or op["resize"][3] < op["resize"][1]) for op in c["ops"])
+        if shrinks:
+            d = np.abs(got.astype(np.float64) - ref)
+            assert d.max() <= 1 and (d > 0).mean() <= 0.02
+        else:
+            assert np.array_equal(got, ref), f"case {i}"                          # the reference's own output
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint8])
+def test_revert_masks_letterbox_undo_1080p(ops, dtype):
+    """The shape the path produces: masks at the 640x640 model input, undone to 1080x1920."""
+    rng = np.random.default_rng(8)
+    m = 12
+    y, x = np.mgrid[0:640, 0:640]
+    src = np.zeros((m, 640, 640), dtype)
+    for i in range(m):
+        cy, cx, ry, rx = rng.uniform(150, 490), rng.uniform(0, 640), rng.uniform(10, 150), rng.uniform(10, 300)
+        src[i] = (((y - cy) / ry) ** 2 + ((x - cx) / rx) ** 2 < 1).astype(dtype)
+    oplist = [{"resize": [640, 360, 1920, 1080]}, {"pad": [0, 0, 140, 140]}]
+    got = ops.revert_masks(torch.from_numpy(src).cuda(), oplist)
+    assert got.shape == (m, 1080, 1920)
+    for i in (0, 5, 11):
+        assert np.array_equal(got[i].cpu().numpy(), OG.revert_mask_to_origin(src[i], oplist))
+    # batch invariance and flip involution
+    one = ops.revert_masks(torch.from_numpy(src[3:4]).cuda(), oplist)
+    assert torch.equal(one[0], got[3])
+    f = [{"flip": [True, True, 1920, 1080]}]
+    assert torch.equal(ops.revert_masks(ops.revert_masks(got, f), f), got)
+    assert torch.equal(ops.revert_masks(got, f), torch.flip(got, [1, 2]))
+    # pad only: centred zero pad and centred crop
+    padded = ops.revert_masks(got[:2], [{"pad": [-3, -4, -5, -6]}])
+    assert padded.shape == (2, 1091, 1927)
+    assert torch.equal(padded[:, 5:5 + 1080, 3:3 + 1920], got[:2]) and padded.sum() == got[:2].sum()
+    cropped = ops.revert_masks(got[:2], [{"pad": [10, 11, 20, 21]}])
+    assert torch.equal(cropped, got[:2, 20:1080 - 21, 10:1920 - 11])
+    with pytest.raises(ValueError):
+        ops.revert_masks(got[:1], [{"pad": [1000, 1000, 0, 0]}])
+    assert ops.revert_masks(got[:0], oplist).shape == (0, 1080, 1920)

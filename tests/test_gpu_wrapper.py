@@ -126,3 +126,40 @@ def test_predict_batch_ragged_frames(models):
         boxes, scores, classes, masks = oracle_postprocess(pred[i:i + 1], proto[i], (256, 256), f.shape[:2], conf, NAMES, 0.4, max_det=30)
         assert np.abs(res['boxes'][i] - boxes).max() <= 1e-3 and res['classes'][i] == classes
         assert res['masks'][i].shape == masks.shape and OM.mask_iou(res['masks'][i], masks) >= 0.999
+
+
+def test_predict_seg_with_operators_reverts_on_device(models):
+    """The reference's calling convention (test_yolov8_model.py:84-117): the caller resizes / pads the frame, passes
+    the operator list, and predict() brings boxes, masks and segments back to sensor space.  Here the revert runs in
+    the HIP kernels for numpy and tensor inputs alike; checked against the oracle's restatement of
+    revert_to_origin / revert_masks_to_origin applied to the oracle's own post-processing result."""
+    _, seg = models
+    rng = np.random.default_rng(4)
+    frame = synth.frames_u8(rng, 1, 256, 256)[0]            # stands for a 480x640 frame resized to 256x144 and padded
+    operators = [{"resize": [256, 144, 640, 360]}, {"pad": [0, 0, 56, 56]}]
+    im = seg.preprocess(frame)
+    y = seg.forward(im)
+    pred, proto = y[0].cpu().numpy(), y[1][-1][0].cpu().numpy()
+    conf = _conf_for(pred)
+    boxes, scores, classes, masks = oracle_postprocess(pred, proto, (256, 256), (256, 256), conf, NAMES, 0.4, max_det=40)
+    assert len(boxes) > 0
+    ref_boxes = OG.revert_to_origin(boxes, operators)
+    ref_masks = OG.revert_masks_to_origin(masks, operators)
+    assert ref_masks.shape[1:] == (360, 640)
+    for as_tensor in (False, True):
+        image = torch.from_numpy(frame).cuda() if as_tensor else frame
+        out, _ = seg.predict(image, conf, operators=operators, iou=0.4, max_det=40)
+        got_boxes, got_masks, got_segs = out['boxes'], out['masks'], out['segments']
+        if as_tensor:
+            assert got_boxes.is_cuda and got_masks.is_cuda and all(s.is_cuda for s in got_segs)
+            got_boxes, got_masks, got_segs = got_boxes.cpu().numpy(), got_masks.cpu().numpy(), [s.cpu().numpy() for s in got_segs]
+        assert np.array_equal(got_boxes, ref_boxes)
+        assert out['classes'] == classes
+        assert got_masks.shape == ref_masks.shape and got_masks.dtype == np.float32
+        # interpolated 0/1 masks: equal wherever the model-space masks agree, i.e. almost everywhere (IoU >= 0.999 there)
+        assert (np.abs(got_masks - ref_masks) > 1e-6).mean() < 2e-3
+        assert len(got_segs) == len(boxes)
+        for s in got_segs:
+            assert s.shape[1] == 2 and (s >= 0).all() and (s == np.round(s)).all()
+            if len(s):
+                assert s[:, 0].max() <= 640 and s[:, 1].max() <= 360 + 140   # contour points of the padded canvas, un-padded then un-resized
