@@ -167,6 +167,19 @@ int lmi_finalize_detections(float *det, const int32_t *count, int batch, int max
                             int32_t *slot_map, int32_t *slot_base, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Keypoints -- replaces `ops.scale_coords(img.shape[2:], pred_kpts,
+ * orig_img.shape)` of `Yolov8Pose.postprocess` (object_detectors/yolov8_lmi/model.py:568-569; in-tree
+ * analogue scale_segments yolov5_trt.py:354-370) on the keypoint columns of the NMS rows, in place:
+ * x -= pad_x, y -= pad_y with gain/pad as Python floats and the pads NOT rounded (unlike scale_boxes),
+ * then /= gain and clip to [0,w0] x [0,h0].  Columns col0 + k*ndim + {0,1} of row i hold keypoint k's
+ * (x, y); a third value (visibility, ndim == 3) is left alone.  Call after lmi_nms_v8 (nm = nkpt*ndim,
+ * col0 = 6); boxes are handled by lmi_finalize_detections as for detection.
+ */
+int lmi_scale_coords(float *det, const int32_t *count, int batch, int max_det, int det_stride,
+                     int col0, int nkpt, int ndim, int model_h, int model_w, const int32_t *orig_hw,
+                     int uniform_h0, int uniform_w0, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Masks -- replaces `ops.process_mask_native(proto[i], pred[:, 6:], pred[:, :4],
  * orig_img.shape[:2])` + `masks[M]` (object_detectors/yolov8_lmi/model.py:235-236; in-tree
  * YOLOv5 analogue yolov5_trt.py:373-415): logits = coef @ proto as a k-ordered fp32 fma chain

@@ -434,6 +434,36 @@ __global__ __launch_bounds__(256) void finalize_slots_kernel(FinalizeParams F) {
   }
 }
 
+// ops.scale_coords on the keypoint columns of the NMS rows, in place: x -= pad_x, y -= pad_y (pads NOT rounded,
+// unlike scale_boxes), /= gain, clip to the original frame.  grid = batch, lanes stride over (row, keypoint).
+struct CoordsParams {
+  float *det;
+  const int *count;
+  int batch, max_det, det_stride, col0, nkpt, ndim;
+  int model_h, model_w;
+  const int *orig_hw;
+  int uh0, uw0;
+};
+
+__global__ __launch_bounds__(256) void scale_coords_kernel(CoordsParams F) {
+  const int b = blockIdx.x;
+  const int n = min(F.count[b], F.max_det);
+  const int h0 = F.orig_hw ? F.orig_hw[2 * b] : F.uh0;
+  const int w0 = F.orig_hw ? F.orig_hw[2 * b + 1] : F.uw0;
+  const double gh = (double)F.model_h / (double)h0, gw = (double)F.model_w / (double)w0;
+  const double gain = gh < gw ? gh : gw;
+  const float fpx = (float)(((double)F.model_w - (double)w0 * gain) / 2.0);
+  const float fpy = (float)(((double)F.model_h - (double)h0 * gain) / 2.0);
+  const float fgain = (float)gain, fw0 = (float)w0, fh0 = (float)h0;
+  for (int e = threadIdx.x; e < n * F.nkpt; e += 256) {
+    const int i = e / F.nkpt, k = e - i * F.nkpt;
+    float *p = F.det + ((size_t)b * F.max_det + i) * F.det_stride + F.col0 + k * F.ndim;
+    const float x = (p[0] - fpx) / fgain, y = (p[1] - fpy) / fgain;
+    p[0] = fminf(fmaxf(x, 0.0f), fw0);
+    p[1] = fminf(fmaxf(y, 0.0f), fh0);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -518,6 +548,22 @@ int lmi_finalize_detections(float *det, const int32_t *count, int batch, int max
   if (mask_slot == nullptr && slot_base == nullptr) return LMI_OK;
   hipLaunchKernelGGL(finalize_slots_kernel, dim3(batch), dim3(256), 0, s, F);
   return lmi_check_launch("finalize_slots_kernel");
+}
+
+int lmi_scale_coords(float *det, const int32_t *count, int batch, int max_det, int det_stride, int col0, int nkpt, int ndim,
+                     int model_h, int model_w, const int32_t *orig_hw, int uniform_h0, int uniform_w0, void *stream) {
+  LMI_REQUIRE(det && count, LMI_ERR_BAD_ARG, "lmi_scale_coords: NULL pointer");
+  LMI_REQUIRE(batch > 0 && batch <= 65535 && max_det > 0 && nkpt > 0 && (ndim == 2 || ndim == 3) && col0 >= 0 &&
+                  det_stride >= col0 + nkpt * ndim,
+              LMI_ERR_BAD_ARG, "lmi_scale_coords: bad shape batch=%d max_det=%d det_stride=%d col0=%d kpt=%dx%d", batch, max_det,
+              det_stride, col0, nkpt, ndim);
+  LMI_REQUIRE(model_h > 0 && model_w > 0, LMI_ERR_BAD_ARG, "lmi_scale_coords: bad model size");
+  LMI_REQUIRE(orig_hw != nullptr || (uniform_h0 > 0 && uniform_w0 > 0), LMI_ERR_BAD_ARG, "lmi_scale_coords: original image size missing");
+  CoordsParams F;
+  F.det = det; F.count = count; F.batch = batch; F.max_det = max_det; F.det_stride = det_stride; F.col0 = col0;
+  F.nkpt = nkpt; F.ndim = ndim; F.model_h = model_h; F.model_w = model_w; F.orig_hw = orig_hw; F.uh0 = uniform_h0; F.uw0 = uniform_w0;
+  hipLaunchKernelGGL(scale_coords_kernel, dim3(batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), F);
+  return lmi_check_launch("scale_coords_kernel");
 }
 
 }  // extern "C"

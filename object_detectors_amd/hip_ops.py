@@ -210,6 +210,22 @@ def finalize_detections(det: torch.Tensor, count: torch.Tensor, nc: int, model_h
     return {"keep": keep, "keep_count": keep_count, "mask_slot": mask_slot, "slot_map": slot_map, "slot_base": slot_base}
 
 
+def scale_coords(det: torch.Tensor, count: torch.Tensor, nkpt: int, ndim: int, model_hw: Tuple[int, int],
+                 orig_hw: Union[Tuple[int, int], torch.Tensor], col0: int = 6) -> torch.Tensor:
+    """`ops.scale_coords` IN PLACE on the keypoint columns det[..., col0 : col0 + nkpt*ndim] of the NMS rows."""
+    _need_cuda(det, "det")
+    b, max_det, stride = det.shape
+    if isinstance(orig_hw, torch.Tensor):
+        _need_cuda(orig_hw, "orig_hw")
+        ohw = orig_hw.to(torch.int32).contiguous()
+        ohw_ptr, uh, uw = ohw.data_ptr(), 0, 0
+    else:
+        ohw_ptr, uh, uw = None, int(orig_hw[0]), int(orig_hw[1])
+    check(_L.lmi_scale_coords(det.data_ptr(), count.data_ptr(), b, max_det, stride, int(col0), int(nkpt), int(ndim),
+                              int(model_hw[0]), int(model_hw[1]), ohw_ptr, uh, uw, _stream()))
+    return det
+
+
 def process_mask(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.Tensor, slot_base: torch.Tensor,
                  orig_hw: Tuple[int, int], capacity: int, out_dtype: torch.dtype = torch.uint8,
                  out: Optional[torch.Tensor] = None, split_events=None):

@@ -89,15 +89,18 @@ class DetectHead(nn.Module):
     """Anchor-free head: per level a box branch (4*reg_max DFL bins) and a class branch."""
     reg_max = 16
 
-    def __init__(self, nc, ch, nm=0):
+    def __init__(self, nc, ch, nm=0, task="detect", kpt_shape=(17, 3)):
         super().__init__()
+        # nm extra channels per anchor: 32 mask coefficients (segment), nkpt*ndim keypoint values (pose), 1 angle (obb)
         self.nc, self.nm, self.nl = nc, nm, len(ch)
+        self.task, self.kpt_shape = task, tuple(kpt_shape)
         c2, c3 = max(16, ch[0] // 4, self.reg_max * 4), max(ch[0], min(nc, 100))
         self.cv2 = nn.ModuleList(nn.Sequential(ConvBNAct(c, c2, 3), ConvBNAct(c2, c2, 3), nn.Conv2d(c2, 4 * self.reg_max, 1)) for c in ch)
         self.cv3 = nn.ModuleList(nn.Sequential(ConvBNAct(c, c3, 3), ConvBNAct(c3, c3, 3), nn.Conv2d(c3, nc, 1)) for c in ch)
         if nm:
             c4 = max(ch[0] // 4, nm)
-            self.proto = Proto(ch[0], 256 if ch[0] >= 64 else max(ch[0], 32), nm)
+            if task == "segment":
+                self.proto = Proto(ch[0], 256 if ch[0] >= 64 else max(ch[0], 32), nm)
             self.cv4 = nn.ModuleList(nn.Sequential(ConvBNAct(c, c4, 3), ConvBNAct(c4, c4, 3), nn.Conv2d(c4, nm, 1)) for c in ch)
         self.strides = (8, 16, 32)
         self.register_buffer("bins", torch.arange(self.reg_max, dtype=torch.float32), persistent=False)
@@ -130,13 +133,26 @@ class DetectHead(nn.Module):
         if not self.nm:
             return y
         mc = torch.cat([self.cv4[i](f).view(bs, self.nm, -1) for i, f in enumerate(feats)], 2)
+        if self.task == "pose":     # keypoints: (raw*2 + anchor - 0.5) * stride, visibility through a sigmoid
+            nk, nd = self.kpt_shape
+            k = mc.view(bs, nk, nd, -1)
+            xy = (k[:, :, :2] * 2.0 + (anchors.view(1, 1, 2, -1) - 0.5)) * strides.view(1, 1, 1, -1)
+            k = torch.cat((xy, k[:, :, 2:].sigmoid()), 2) if nd == 3 else xy
+            return torch.cat((y, k.reshape(bs, nk * nd, -1)), 1), (feats, mc)
+        if self.task == "obb":      # angle in [-pi/4, 3pi/4)
+            angle = (mc.sigmoid() - 0.25) * math.pi
+            return torch.cat((y, angle), 1), (feats, angle)
         p = self.proto(feats[0])
         return torch.cat((y, mc), 1), (feats, mc, p)
 
 
 class YoloV8(nn.Module):
-    def __init__(self, scale="n", nc=80, seg=False, names: Dict[int, str] = None):
+    def __init__(self, scale="n", nc=80, seg=False, names: Dict[int, str] = None, task: str = None, kpt_shape=(17, 3)):
         super().__init__()
+        task = task or ("segment" if seg else "detect")
+        if task not in ("detect", "segment", "pose", "obb"):
+            raise ValueError(f"unknown task {task}")
+        seg = task == "segment"
         d, w, mc = SCALES[scale]
         ch = lambda c: int(math.ceil(min(c, mc) * w / 8) * 8)
         n = lambda k: max(round(k * d), 1)
@@ -157,9 +173,10 @@ class YoloV8(nn.Module):
         self.n18 = C2f(c3 + c4, c4, n(3))
         self.n19 = ConvBNAct(c4, c4, 3, 2)
         self.n21 = C2f(c4 + c5, c5, n(3))
-        self.head = DetectHead(nc, (c3, c4, c5), 32 if seg else 0)
+        extra = {"detect": 0, "segment": 32, "pose": kpt_shape[0] * kpt_shape[1], "obb": 1}[task]
+        self.head = DetectHead(nc, (c3, c4, c5), extra, task, kpt_shape)
         self.head.bias_init()
-        self.nc, self.seg, self.scale = nc, seg, scale
+        self.nc, self.seg, self.scale, self.task, self.kpt_shape = nc, seg, scale, task, list(kpt_shape)
         self.names = names or {i: f"class{i}" for i in range(nc)}
         self.fp16 = False
         self.stride = 32
@@ -176,12 +193,13 @@ class YoloV8(nn.Module):
         return self.head([n3, m4, m5])
 
 
-def save_checkpoint(path: str, scale="n", nc=80, seg=False, names=None, seed=0) -> None:
+def save_checkpoint(path: str, scale="n", nc=80, seg=False, names=None, seed=0, task=None, kpt_shape=(17, 3)) -> None:
     """Random-init weights in this package's checkpoint format (tensors + plain metadata only, so it
     loads with torch.load(weights_only=True))."""
     torch.manual_seed(seed)
-    m = YoloV8(scale, nc, seg, names)
-    torch.save({"format": "lmi-yolov8-torch", "scale": scale, "nc": nc, "seg": bool(seg),
+    m = YoloV8(scale, nc, seg, names, task, kpt_shape)
+    torch.save({"format": "lmi-yolov8-torch", "scale": scale, "nc": nc, "seg": bool(m.seg), "task": m.task,
+                "kpt_shape": [int(v) for v in m.kpt_shape],
                 "names": {int(k): str(v) for k, v in m.names.items()}, "state_dict": m.state_dict()}, path)
 
 
@@ -189,7 +207,7 @@ def load_checkpoint(path: str, device, fp16=False) -> YoloV8:
     ck = torch.load(path, map_location="cpu", weights_only=True)
     if not isinstance(ck, dict) or ck.get("format") != "lmi-yolov8-torch":
         raise ValueError(f"{path} is not an lmi-yolov8-torch checkpoint (ultralytics .pt files need the ultralytics package)")
-    m = YoloV8(ck["scale"], ck["nc"], ck["seg"], ck["names"])
+    m = YoloV8(ck["scale"], ck["nc"], ck["seg"], ck["names"], ck.get("task"), tuple(ck.get("kpt_shape", (17, 3))))
     m.load_state_dict(ck["state_dict"])
     m.eval().to(device)
     if fp16:

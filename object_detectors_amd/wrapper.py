@@ -357,3 +357,89 @@ class Yolov8Core:
                 image[y1:y2 + 1, x1:x1 + t] = color
                 image[y1:y2 + 1, max(x2 - t + 1, 0):x2 + 1] = color
         return image
+
+
+class Yolov8PoseCore(Yolov8Core):
+    """Keypoint models (object_detectors/yolov8_lmi/model.py:535-657; twin ultralytics_lmi/yolo/model.py): the same
+    NMS rows carry nkpt*ndim keypoint values instead of mask coefficients.
+      postprocess :542-588 -> lmi_nms_v8 + lmi_finalize_detections + lmi_scale_coords, one device->host copy
+      predict     :592-657 -> unchanged control flow; keypoints of all objects reverted in one call"""
+
+    @torch.inference_mode()
+    def postprocess(self, preds, img, orig_imgs, conf: Union[float, dict], iou=0.45, agnostic=False, max_det=300):
+        if isinstance(preds, (list, tuple)):
+            preds = preds[0]
+        if not isinstance(preds, torch.Tensor):
+            raise TypeError(f'Prediction type {type(preds)} not supported')
+        self._require_gpu('postprocess')
+        ops = _hip_ops()
+        nc = len(self.model.names)
+        nkpt, ndim = (int(v) for v in self.model.kpt_shape)
+        if preds.shape[1] != 4 + nc + nkpt * ndim:
+            raise ValueError(f'prediction has {preds.shape[1]} channels, expected 4+{nc}+{nkpt}*{ndim}')
+        conf2 = self.get_min_conf(conf)
+        thres = self._class_thresholds(conf)
+        preds = preds.to(self.device)
+        B = preds.shape[0]
+        model_hw = tuple(img.shape[2:])
+        shapes = [tuple((orig_imgs[i] if isinstance(orig_imgs, list) else orig_imgs).shape[:2]) for i in range(B)]
+        ohw = shapes[0] if all(s == shapes[0] for s in shapes) else torch.tensor(shapes, dtype=torch.int32, device=self.device)
+        det, count, _ = ops.nms_v8(preds, float(conf2), float(iou), agnostic=bool(agnostic), max_det=int(max_det), nc=nc)
+        fin = ops.finalize_detections(det, count, nc, model_hw, ohw, thres, with_slots=False)
+        ops.scale_coords(det, count, nkpt, ndim, model_hw, ohw)
+        count_h = count.cpu().numpy()
+        keep_h = fin["keep"].cpu().numpy().astype(bool)
+        det_h = det.cpu().numpy()
+        results = collections.defaultdict(list)
+        names = self.model.names
+        for i in range(B):
+            orig_img = orig_imgs[i] if isinstance(orig_imgs, list) else orig_imgs
+            n = int(count_h[i])
+            if n == 0:
+                continue
+            M = keep_h[i, :n]
+            classes = np.array([names[int(c)] for c in det_h[i, :n, 5]])
+            if isinstance(orig_img, torch.Tensor):
+                sel = torch.from_numpy(np.nonzero(M)[0]).to(det.device)
+                rows = det[i, :n][sel]
+                results['boxes'].append(rows[:, :4])
+                results['scores'].append(rows[:, 4])
+                results['points'].append(rows[:, 6:].reshape(len(sel), nkpt, ndim))
+            else:
+                rows = det_h[i, :n][M]
+                results['boxes'].append(rows[:, :4])
+                results['scores'].append(rows[:, 4])
+                results['points'].append(rows[:, 6:].reshape(len(rows), nkpt, ndim))
+            results['classes'].append(classes[M].tolist())
+        return results
+
+    @torch.inference_mode()
+    def predict(self, image, configs, operators=[], iou=0.4, agnostic=False, max_det=300):
+        import gadget_utils.pipeline_utils as pipeline_utils
+        time_info = {}
+        t0 = time.time()
+        im = self.preprocess(image)
+        time_info['preproc'] = time.time() - t0
+        t0 = time.time()
+        pred = self.forward(im)
+        time_info['proc'] = time.time() - t0
+        t0 = time.time()
+        results = self.postprocess(pred, im, image, configs, iou, agnostic, max_det)
+        results_dict = collections.defaultdict(list)
+        if not len(results['boxes']):
+            time_info['postproc'] = time.time() - t0
+            return results_dict, time_info
+        boxes, scores, classes, points = results['boxes'][0], results['scores'][0], results['classes'][0], results['points'][0]
+        if len(points) and points.shape[-1] == 3:     # visibility is dropped (model.py:643-645)
+            points = points[:, :, :-1]
+        n, nkpt = points.shape[0], points.shape[1]
+        if n:   # every keypoint of every object in one call instead of one call per object (model.py:648)
+            flat = points.reshape(n * nkpt, 2)
+            flat = flat.contiguous() if isinstance(flat, torch.Tensor) else np.ascontiguousarray(flat)
+            points = pipeline_utils.revert_to_origin(flat, operators).reshape(n, nkpt, 2)
+        results_dict['points'] = points
+        results_dict['boxes'] = pipeline_utils.revert_to_origin(boxes, operators)
+        results_dict['scores'] = scores
+        results_dict['classes'] = classes
+        time_info['postproc'] = time.time() - t0
+        return results_dict, time_info

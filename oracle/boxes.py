@@ -69,3 +69,23 @@ def class_filter(confs: np.ndarray, cls_ids: np.ndarray, thres_per_class: np.nda
     """M = confs > thres[cls] with the comparison done in float64 (model.py:232)."""
     t = thres_per_class[cls_ids.astype(np.int64)]
     return confs.astype(np.float64) > t
+
+
+def scale_coords(img1_shape, coords: np.ndarray, img0_shape) -> np.ndarray:
+    """ultralytics 8.3.x `ops.scale_coords(img1_shape, coords, img0_shape)` (normalize=False, padding=True) as
+    called by Yolov8Pose.postprocess (object_detectors/yolov8_lmi/model.py:569; in-tree analogue
+    scale_segments yolov5_trt.py:354-370): gain = min(h1/h0, w1/w0) and pad = ((w1 - w0*gain)/2, (h1 - h0*gain)/2)
+    are Python floats -- the pads are NOT rounded here, unlike scale_boxes -- applied to the fp32 tensor in place
+    (x -= pad_x, y -= pad_y, x /= gain, y /= gain), then clipped to [0,w0] x [0,h0].  PARITY UNPINNED against
+    ultralytics (not installed); the op sequence is checked against torch-CPU executing it (tests/test_oracle_nms.py).
+    coords (..., 2|3): a third component (visibility) passes through."""
+    h1, w1 = img1_shape[:2]
+    h0, w0 = img0_shape[:2]
+    gain = min(h1 / h0, w1 / w0)
+    pad = (w1 - w0 * gain) / 2, (h1 - h0 * gain) / 2
+    c = np.array(coords, dtype=F32, copy=True)
+    c[..., 0] = (c[..., 0] - F32(pad[0])) / F32(gain)
+    c[..., 1] = (c[..., 1] - F32(pad[1])) / F32(gain)
+    c[..., 0] = np.clip(c[..., 0], F32(0), F32(w0))
+    c[..., 1] = np.clip(c[..., 1], F32(0), F32(h0))
+    return c

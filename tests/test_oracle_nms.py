@@ -227,3 +227,27 @@ def test_class_filter_float64_compare_and_dict():
     m = B.class_filter(confs, cls, thr)
     ref = torch.from_numpy(confs) > torch.tensor(thr[cls.astype(int)])
     assert m.tolist() == ref.tolist() == [True, True, True, False]
+
+
+def _scale_coords_torch(img1_shape, coords, img0_shape):
+    """ops.scale_coords' 8.3.x op sequence executed by torch-CPU (fp32 tensor, python scalars, pads not rounded)."""
+    gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+    pad = (img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2
+    c = torch.from_numpy(coords.copy())
+    c[..., 0] -= pad[0]
+    c[..., 1] -= pad[1]
+    c[..., 0] /= gain
+    c[..., 1] /= gain
+    c[..., 0] = c[..., 0].clamp(0, img0_shape[1])
+    c[..., 1] = c[..., 1].clamp(0, img0_shape[0])
+    return c.numpy()
+
+
+@pytest.mark.parametrize("h0,w0,S,ndim", [(1080, 1920, 640, 3), (427, 640, 640, 2), (375, 500, 640, 3), (889, 1333, 640, 3), (640, 640, 640, 2)])
+def test_scale_coords_matches_torch_ops(h0, w0, S, ndim):
+    rng = np.random.default_rng(w0)
+    k = (rng.random((40, 17, ndim)).astype(F32) * (S + 40) - 20).astype(F32)
+    got = B.scale_coords((S, S), k, (h0, w0, 3))
+    assert np.array_equal(got, _scale_coords_torch((S, S), k, (h0, w0, 3)))
+    if ndim == 3:
+        assert np.array_equal(got[..., 2], k[..., 2])
