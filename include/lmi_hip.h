@@ -167,6 +167,28 @@ int lmi_finalize_detections(float *det, const int32_t *count, int batch, int max
                             int32_t *slot_map, int32_t *slot_base, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Oriented boxes -- replaces, in `Yolov8Obb.postprocess`
+ * (object_detectors/yolov8_lmi/model.py:398-465):
+ *   lmi_nms_v8_rotated  `ops.non_max_suppression(preds, conf2, iou, agnostic=, max_det=, nc=, rotated=True)` :423.
+ *     Same arguments as lmi_nms_v8; pred is (batch, 4+nc+nm, anchors) with xywh boxes and the angle as
+ *     the LAST of the nm >= 1 extra channels.  Rows come out as [x, y, w, h, conf, cls, extras...]
+ *     (no xyxy conversion).  Suppression is ultralytics' `nms_rotated`: a candidate is dropped when its
+ *     probiou with ANY higher-scored candidate (kept or not) is >= iou_thres -- not a greedy pass.
+ *   lmi_finalize_obb  `regularize_rboxes` :436, `scale_boxes(..., xywh=True)` :438, `xywhr2xyxyxyxy` :446
+ *     and `M = confs > thres` :448-455.  det is NOT modified; corners [device] fp32 (batch, max_det, 4, 2)
+ *     receive the four corner points of rows i < count[b]; keep / keep_count / thres as in
+ *     lmi_finalize_detections.  The angle is read from column det_stride-1.
+ */
+int lmi_nms_v8_rotated(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres,
+                       double iou_thres, int agnostic, int max_det, int max_nms, float max_wh,
+                       float *out_det, int32_t *out_count, int32_t *out_anchor, void *workspace,
+                       int64_t workspace_bytes, void *stream);
+int lmi_finalize_obb(const float *det, const int32_t *count, int batch, int max_det, int det_stride,
+                     int nc, int model_h, int model_w, const int32_t *orig_hw, int uniform_h0,
+                     int uniform_w0, const double *thres, double uniform_thres, float *corners,
+                     uint8_t *keep, int32_t *keep_count, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Keypoints -- replaces `ops.scale_coords(img.shape[2:], pred_kpts,
  * orig_img.shape)` of `Yolov8Pose.postprocess` (object_detectors/yolov8_lmi/model.py:568-569; in-tree
  * analogue scale_segments yolov5_trt.py:354-370) on the keypoint columns of the NMS rows, in place:

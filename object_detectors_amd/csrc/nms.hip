@@ -44,7 +44,7 @@ __device__ __forceinline__ float sortable2f(uint32_t s) {
 }
 
 struct NmsLayout {
-  size_t off_count, off_keys, off_cls, off_sbox, total;
+  size_t off_count, off_keys, off_cls, off_sbox, off_cd, total;
   int P;
 };
 
@@ -58,6 +58,7 @@ NmsLayout nms_layout(int batch, int anchors) {
   L.off_keys = o;  o = align_up(o + sizeof(uint64_t) * (size_t)batch * L.P, 256);
   L.off_cls = o;   o = align_up(o + sizeof(int) * (size_t)batch * anchors, 256);
   L.off_sbox = o;  o = align_up(o + sizeof(float4) * (size_t)batch * anchors, 256);
+  L.off_cd = o;    o = align_up(o + sizeof(float2) * (size_t)batch * anchors, 256);  // rotated NMS only
   L.total = o;
   return L;
 }
@@ -200,6 +201,7 @@ struct SortNmsParams {
   int *out_anchor;
   int lds_keys;  // capacity (keys) of the LDS sort buffer
   int lbox_off;  // byte offset of the LDS box buffer (lds_keys float4)
+  float2 *scd;   // rotated: covariance c and determinant per sorted candidate (global copy)
 };
 
 __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams S) {
@@ -337,6 +339,135 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Rotated boxes: `non_max_suppression(rotated=True)` -> `nms_rotated` (ultralytics 8.3.x; semantics and formula
+// in oracle/obb.py).  Same sort as above, then NOT a greedy pass: candidate j (in score order) is kept iff
+// probiou(i, j) < thr for EVERY higher-scored i, kept or not, so the columns are independent: lane j walks i < j
+// and leaves at the first hit.  Per candidate the class-offset centre, the covariance terms a, b, c of its
+// ellipse and max(ab - c^2, 0) are computed once.  Rows come out as [x, y, w, h, conf, cls, extras..., angle].
+__device__ __forceinline__ float probiou(float x1, float y1, float a1, float b1, float c1, float d1, float x2, float y2,
+                                         float a2, float b2, float c2, float d2) {
+  const float eps = 1e-7f;
+  const float sa = a1 + a2, sb = b1 + b2, sc = c1 + c2;
+  const float det = sa * sb - sc * sc;
+  const float den = det + eps;
+  const float dy = y1 - y2, dx = x1 - x2;
+  const float t1 = ((sa * (dy * dy) + sb * (dx * dx)) / den) * 0.25f;
+  const float t2 = (((sc * (x2 - x1)) * (y1 - y2)) / den) * 0.5f;
+  const float t3 = logf(det / (4.0f * sqrtf(d1 * d2) + eps) + eps) * 0.5f;
+  float bd = t1 + t2 + t3;
+  bd = fminf(fmaxf(bd, eps), 100.0f);
+  const float hd = sqrtf(1.0f - expf(-bd) + eps);
+  return 1.0f - hd;
+}
+
+__global__ __launch_bounds__(kSortThreads) void nms_sort_rotated(SortNmsParams S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t *lkeys = reinterpret_cast<uint64_t *>(smem);
+  const int md = (S.max_det + 1) & ~1;
+  int *kpos = reinterpret_cast<int *>(smem + (size_t)S.lds_keys * 8);
+  int *wcnt = kpos + md;  // 16 wave counts + running total
+  float4 *lbox = reinterpret_cast<float4 *>(smem + S.lbox_off);   // x + off, y + off, a, b
+  float2 *lcd = reinterpret_cast<float2 *>(lbox + S.lds_keys);     // c, max(ab - c^2, 0)
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int A = S.A, C = 4 + S.nc + S.nm;
+  const float *pb = S.pred + (size_t)b * C * A;
+  uint64_t *gkeys = S.keys + (size_t)b * S.P;
+
+  const int n = min(S.cand_count[b], A);
+  if (n == 0) {
+    if (tid == 0) S.out_count[b] = 0;
+    return;
+  }
+  const int P2 = next_pow2(n);
+  const bool in_lds = P2 <= S.lds_keys;
+  if (in_lds) {
+    for (int i = tid; i < P2; i += kSortThreads) lkeys[i] = (i < n) ? gkeys[i] : 0ull;
+    __syncthreads();
+    bitonic_desc(lkeys, P2);
+  } else {
+    for (int i = n + tid; i < P2; i += kSortThreads) gkeys[i] = 0ull;
+    __syncthreads();
+    bitonic_desc(gkeys, P2);
+  }
+  uint64_t *keys = in_lds ? lkeys : gkeys;
+  float4 *box = in_lds ? lbox : S.sbox + (size_t)b * A;
+  float2 *cd = in_lds ? lcd : S.scd + (size_t)b * A;
+  const int n_eff = min(n, S.max_nms);
+
+  for (int i = tid; i < n_eff; i += kSortThreads) {
+    const uint32_t anchor = ~(uint32_t)keys[i];
+    const float x = pb[anchor], y = pb[(size_t)A + anchor], w = pb[(size_t)2 * A + anchor], h = pb[(size_t)3 * A + anchor];
+    const float ang = pb[(size_t)(C - 1) * A + anchor];
+    const float off = S.agnostic ? 0.0f : (float)S.cls_of[(size_t)b * A + anchor] * S.max_wh;
+    const float w2 = w * w / 12.0f, h2 = h * h / 12.0f;
+    const float cs = cosf(ang), sn = sinf(ang);
+    const float cos2 = cs * cs, sin2 = sn * sn;
+    const float ca = w2 * cos2 + h2 * sin2, cb = w2 * sin2 + h2 * cos2, cc = ((w2 - h2) * cs) * sn;
+    box[i] = make_float4(x + off, y + off, ca, cb);
+    cd[i] = make_float2(cc, fmaxf(ca * cb - cc * cc, 0.0f));
+  }
+  __syncthreads();
+
+  // column j is dropped unless every earlier (higher-scored) box has probiou < thr; the decision is parked in bit 31
+  // of the key's anchor word (~anchor has it set: anchors < 2^24), cleared = dropped
+  for (int j = tid; j < n_eff; j += kSortThreads) {
+    const float4 bj = box[j];
+    const float2 cj = cd[j];
+    bool keep = true;
+    for (int i = 0; i < j; ++i) {
+      const float4 bi = box[i];
+      const float2 ci = cd[i];
+      const float v = probiou(bi.x, bi.y, bi.z, bi.w, ci.x, ci.y, bj.x, bj.y, bj.z, bj.w, cj.x, cj.y);
+      if (!(v < S.iou_thr)) { keep = false; break; }
+    }
+    if (!keep) keys[j] &= ~(1ull << 31);
+  }
+  if (tid == 0) wcnt[16] = 0;
+  __syncthreads();
+
+  // ordered compaction of the survivors, first max_det of them
+  for (int base = 0; base < n_eff; base += kSortThreads) {
+    const int K = wcnt[16];
+    if (K >= S.max_det) break;
+    const int j = base + tid;
+    const bool k = j < n_eff && ((keys[j] >> 31) & 1ull);
+    const uint64_t m = __ballot(k);
+    if (lane == 0) wcnt[wave] = __builtin_popcountll(m);
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < kSortThreads / 64; ++w) {
+      const int t = wcnt[w];
+      if (w < wave) before += t;
+      total += t;
+    }
+    const int idx = K + before + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (k && idx < S.max_det) kpos[idx] = j;
+    __syncthreads();
+    if (tid == 0) wcnt[16] = min(K + total, S.max_det);
+    __syncthreads();
+  }
+  const int K = wcnt[16];
+
+  if (tid == 0) S.out_count[b] = K;
+  const int row = 6 + S.nm;
+  float *od = S.out_det + (size_t)b * S.max_det * row;
+  for (int e = tid; e < K * row; e += kSortThreads) {
+    const int t = e / row, col = e - t * row;
+    const uint64_t key = keys[kpos[t]];
+    const uint32_t anchor = ~(uint32_t)key & 0x7fffffffu;
+    float v;
+    if (col < 4) v = pb[(size_t)col * A + anchor];
+    else if (col == 4) v = sortable2f((uint32_t)(key >> 32));
+    else if (col == 5) v = (float)S.cls_of[(size_t)b * A + anchor];
+    else v = pb[(size_t)(4 + S.nc + (col - 6)) * A + anchor];
+    od[e] = v;
+    if (col == 0) S.out_anchor[(size_t)b * S.max_det + t] = (int)anchor;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 struct FinalizeParams {
   float *det;
   const int *count;
@@ -464,6 +595,76 @@ __global__ __launch_bounds__(256) void scale_coords_kernel(CoordsParams F) {
   }
 }
 
+// Yolov8Obb.postprocess after NMS (object_detectors/yolov8_lmi/model.py:436-455; formulas in oracle/obb.py):
+// regularize_rboxes -> scale_boxes(xywh=True) + clip -> xywhr2xyxyxyxy, and the per-class threshold.  The NMS rows
+// are left untouched (the reference builds the corner boxes from a copy).  grid = batch, lane = detection.
+struct ObbParams {
+  const float *det;
+  const int *count;
+  int batch, max_det, det_stride, nc, angle_col;
+  int model_h, model_w;
+  const int *orig_hw;
+  int uh0, uw0;
+  const double *thres;
+  double uniform_thres;
+  float *corners;  // (batch, max_det, 4, 2)
+  uint8_t *keep;
+  int *keep_count;
+};
+
+__global__ __launch_bounds__(1024) void finalize_obb_kernel(ObbParams F) {
+  __shared__ int wtot[16];
+  const int b = blockIdx.x;
+  const int i = threadIdx.x, lane = i & 63, wave = i >> 6, nwaves = blockDim.x >> 6;
+  const int n = min(F.count[b], F.max_det);
+  const int h0 = F.orig_hw ? F.orig_hw[2 * b] : F.uh0;
+  const int w0 = F.orig_hw ? F.orig_hw[2 * b + 1] : F.uw0;
+  bool k = false;
+  if (i < n) {
+    const float *d = F.det + ((size_t)b * F.max_det + i) * F.det_stride;
+    float x = d[0], y = d[1];
+    const float w = d[2], h = d[3], conf = d[4];
+    const int c = (int)d[5];
+    float t = d[F.angle_col];
+    // regularize_rboxes: longer edge first, angle into [0, pi)
+    const float kPi = 3.14159265358979323846f, kHalfPi = 1.57079632679489661923f;
+    const bool wide = w > h;
+    float w_ = wide ? w : h, h_ = wide ? h : w;
+    t = wide ? t : t + kHalfPi;
+    float m = fmodf(t, kPi);              // torch's % : fmod, then shifted into the divisor's sign
+    if (m != 0.0f && m < 0.0f) m += kPi;
+    t = m;
+    // scale_boxes(xywh=True): pads rounded as for xyxy boxes, only the centre is shifted; clip_boxes clamps all 4 columns
+    const double gh = (double)F.model_h / (double)h0, gw = (double)F.model_w / (double)w0;
+    const double gain = gh < gw ? gh : gw;
+    const float fpx = (float)py_round(((double)F.model_w - (double)w0 * gain) / 2.0 - 0.1);
+    const float fpy = (float)py_round(((double)F.model_h - (double)h0 * gain) / 2.0 - 0.1);
+    const float fgain = (float)gain, fw0 = (float)w0, fh0 = (float)h0;
+    x = fminf(fmaxf((x - fpx) / fgain, 0.0f), fw0);
+    y = fminf(fmaxf((y - fpy) / fgain, 0.0f), fh0);
+    w_ = fminf(fmaxf(w_ / fgain, 0.0f), fw0);
+    h_ = fminf(fmaxf(h_ / fgain, 0.0f), fh0);
+    // xywhr2xyxyxyxy
+    const float cs = cosf(t), sn = sinf(t);
+    const float hw = w_ / 2.0f, nhh = (-h_) / 2.0f, hh = h_ / 2.0f;
+    const float v1x = hw * cs, v1y = hw * sn, v2x = nhh * sn, v2y = hh * cs;
+    float *o = F.corners + ((size_t)b * F.max_det + i) * 8;
+    o[0] = (x + v1x) + v2x; o[1] = (y + v1y) + v2y;
+    o[2] = (x + v1x) - v2x; o[3] = (y + v1y) - v2y;
+    o[4] = (x - v1x) - v2x; o[5] = (y - v1y) - v2y;
+    o[6] = (x - v1x) + v2x; o[7] = (y - v1y) + v2y;
+    const double th = F.thres ? ((c >= 0 && c < F.nc) ? F.thres[c] : 1.0) : F.uniform_thres;
+    k = (double)conf > th;
+  }
+  const uint64_t mask = __ballot(k);
+  if (lane == 0) wtot[wave] = __builtin_popcountll(mask);
+  __syncthreads();
+  int total = 0;
+  for (int w = 0; w < nwaves; ++w) total += wtot[w];
+  if (i < F.max_det) F.keep[(size_t)b * F.max_det + i] = k ? 1 : 0;
+  if (i == 0) F.keep_count[b] = total;
+}
+
 }  // namespace
 
 extern "C" {
@@ -473,9 +674,9 @@ int64_t lmi_nms_workspace_bytes(int batch, int anchors) {
   return (int64_t)nms_layout(batch, anchors).total;
 }
 
-int lmi_nms_v8(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres, double iou_thres,
-               int agnostic, int max_det, int max_nms, float max_wh, float *out_det, int32_t *out_count,
-               int32_t *out_anchor, void *workspace, int64_t workspace_bytes, void *stream) {
+static int nms_common(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres, double iou_thres,
+                      int agnostic, int max_det, int max_nms, float max_wh, float *out_det, int32_t *out_count,
+                      int32_t *out_anchor, void *workspace, int64_t workspace_bytes, void *stream, int rotated) {
   LMI_REQUIRE(pred && out_det && out_count && out_anchor && workspace, LMI_ERR_BAD_ARG, "lmi_nms_v8: NULL pointer");
   LMI_REQUIRE(batch > 0 && batch <= 65535 && nc > 0 && nm >= 0 && anchors > 0, LMI_ERR_BAD_ARG,
               "lmi_nms_v8: bad shape batch=%d nc=%d nm=%d anchors=%d", batch, nc, nm, anchors);
@@ -508,21 +709,46 @@ int lmi_nms_v8(const float *pred, int batch, int nc, int nm, int anchors, float 
   int rc = lmi_check_launch("nms_decode_filter");
   if (rc) return rc;
 
-  // torchvision compares the fp32 IoU against the threshold as a double: use the largest fp32 <= thr
+  // torchvision compares the fp32 IoU against the threshold as a double: use the largest fp32 <= thr.
+  // nms_rotated compares `ious.max(0) < threshold` in fp32 (tensor vs Python float): the threshold rounded to fp32.
   float thr = (float)iou_thres;
-  if ((double)thr > iou_thres) thr = std::nextafterf(thr, -INFINITY);
+  if (!rotated && (double)thr > iou_thres) thr = std::nextafterf(thr, -INFINITY);
 
   SortNmsParams S;
   S.pred = pred; S.nc = nc; S.nm = nm; S.A = anchors; S.iou_thr = thr; S.agnostic = agnostic ? 1 : 0;
   S.max_det = max_det; S.max_nms = max_nms; S.max_wh = max_wh; S.keys = keys; S.P = L.P; S.cls_of = cls_of;
   S.sbox = sbox; S.cand_count = cand_count; S.out_det = out_det; S.out_count = out_count; S.out_anchor = out_anchor;
   S.lds_keys = L.P < kSortLdsCap ? L.P : kSortLdsCap;
+  S.scd = reinterpret_cast<float2 *>(ws + L.off_cd);
+  if (rotated) {
+    LMI_REQUIRE(nm >= 1, LMI_ERR_BAD_ARG, "lmi_nms_v8_rotated: the angle must be the last of nm >= 1 extra channels");
+    const size_t head = (size_t)S.lds_keys * 8 + 4 * (size_t)((max_det + 1) & ~1) + 4 * 17 + 16;
+    S.lbox_off = (int)((head + 15) & ~(size_t)15);
+    const size_t lds_rot = (size_t)S.lbox_off + (size_t)S.lds_keys * (16 + 8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_rotated), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(nms_sort_rotated, dim3(batch), dim3(kSortThreads), lds_rot, s, S);
+    return lmi_check_launch("nms_sort_rotated");
+  }
   const size_t lds_small = (size_t)S.lds_keys * 8 + 4 * 6 * (size_t)((max_det + 1) & ~1) + 64 * 8 + 64 * 4 + 16;
   S.lbox_off = (int)((lds_small + 15) & ~(size_t)15);
   const size_t lds = (size_t)S.lbox_off + (size_t)S.lds_keys * 16;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_suppress), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(nms_sort_suppress, dim3(batch), dim3(kSortThreads), lds, s, S);
   return lmi_check_launch("nms_sort_suppress");
+}
+
+int lmi_nms_v8(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres, double iou_thres,
+               int agnostic, int max_det, int max_nms, float max_wh, float *out_det, int32_t *out_count,
+               int32_t *out_anchor, void *workspace, int64_t workspace_bytes, void *stream) {
+  return nms_common(pred, batch, nc, nm, anchors, conf_thres, iou_thres, agnostic, max_det, max_nms, max_wh, out_det, out_count,
+                    out_anchor, workspace, workspace_bytes, stream, 0);
+}
+
+int lmi_nms_v8_rotated(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres, double iou_thres,
+                       int agnostic, int max_det, int max_nms, float max_wh, float *out_det, int32_t *out_count,
+                       int32_t *out_anchor, void *workspace, int64_t workspace_bytes, void *stream) {
+  return nms_common(pred, batch, nc, nm, anchors, conf_thres, iou_thres, agnostic, max_det, max_nms, max_wh, out_det, out_count,
+                    out_anchor, workspace, workspace_bytes, stream, 1);
 }
 
 int lmi_finalize_detections(float *det, const int32_t *count, int batch, int max_det, int det_stride, int nc, int model_h,
@@ -564,6 +790,24 @@ int lmi_scale_coords(float *det, const int32_t *count, int batch, int max_det, i
   F.nkpt = nkpt; F.ndim = ndim; F.model_h = model_h; F.model_w = model_w; F.orig_hw = orig_hw; F.uh0 = uniform_h0; F.uw0 = uniform_w0;
   hipLaunchKernelGGL(scale_coords_kernel, dim3(batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), F);
   return lmi_check_launch("scale_coords_kernel");
+}
+
+int lmi_finalize_obb(const float *det, const int32_t *count, int batch, int max_det, int det_stride, int nc, int model_h,
+                     int model_w, const int32_t *orig_hw, int uniform_h0, int uniform_w0, const double *thres,
+                     double uniform_thres, float *corners, uint8_t *keep, int32_t *keep_count, void *stream) {
+  LMI_REQUIRE(det && count && corners && keep && keep_count, LMI_ERR_BAD_ARG, "lmi_finalize_obb: NULL pointer");
+  LMI_REQUIRE(batch > 0 && batch <= 65535 && max_det > 0 && det_stride >= 7 && nc > 0, LMI_ERR_BAD_ARG,
+              "lmi_finalize_obb: bad shape batch=%d max_det=%d det_stride=%d nc=%d", batch, max_det, det_stride, nc);
+  LMI_REQUIRE(max_det <= LMI_MAX_DET_CAP, LMI_ERR_LIMIT, "lmi_finalize_obb: max_det %d > %d", max_det, LMI_MAX_DET_CAP);
+  LMI_REQUIRE(model_h > 0 && model_w > 0, LMI_ERR_BAD_ARG, "lmi_finalize_obb: bad model size");
+  LMI_REQUIRE(orig_hw != nullptr || (uniform_h0 > 0 && uniform_w0 > 0), LMI_ERR_BAD_ARG, "lmi_finalize_obb: original image size missing");
+  ObbParams F;
+  F.det = det; F.count = count; F.batch = batch; F.max_det = max_det; F.det_stride = det_stride; F.nc = nc;
+  F.angle_col = det_stride - 1;  // the angle is the last extra channel of the row
+  F.model_h = model_h; F.model_w = model_w; F.orig_hw = orig_hw; F.uh0 = uniform_h0; F.uw0 = uniform_w0;
+  F.thres = thres; F.uniform_thres = uniform_thres; F.corners = corners; F.keep = keep; F.keep_count = keep_count;
+  hipLaunchKernelGGL(finalize_obb_kernel, dim3(batch), dim3((max_det + 63) / 64 * 64), 0, reinterpret_cast<hipStream_t>(stream), F);
+  return lmi_check_launch("finalize_obb_kernel");
 }
 
 }  // extern "C"

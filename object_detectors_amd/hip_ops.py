@@ -135,8 +135,9 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
 
 
 def nms_v8(pred: torch.Tensor, conf_thres: float, iou_thres: float = 0.45, agnostic: bool = False, max_det: int = 300,
-           nc: int = 0, max_nms: int = 30000, max_wh: float = 7680.0, out=None):
-    """`ops.non_max_suppression` on the head output (B, 4+nc+nm, A) fp32.
+           nc: int = 0, max_nms: int = 30000, max_wh: float = 7680.0, out=None, rotated: bool = False):
+    """`ops.non_max_suppression` on the head output (B, 4+nc+nm, A) fp32.  rotated=True: oriented boxes
+    (xywh + angle as the last extra channel, ultralytics' nms_rotated on probiou), rows stay xywh.
 
     Returns (det (B,max_det,6+nm) fp32, count (B,) int32, anchor (B,max_det) int32), all on the
     device; rows >= count[b] are unspecified.  `out` = a previous result tuple of the same shapes
@@ -161,10 +162,40 @@ def nms_v8(pred: torch.Tensor, conf_thres: float, iou_thres: float = 0.45, agnos
         anchor = torch.empty((b, max_det), dtype=torch.int32, device=pred.device)
     nbytes = int(_L.lmi_nms_workspace_bytes(b, a))
     ws = _ws.get(pred.device, "nms", nbytes)
-    check(_L.lmi_nms_v8(pred.data_ptr(), b, nc, nm, a, float(conf_thres), float(iou_thres), int(agnostic), int(max_det),
-                        int(max_nms), float(max_wh), det.data_ptr(), count.data_ptr(), anchor.data_ptr(), ws.data_ptr(),
-                        ws.numel(), _stream()))
+    fn = _L.lmi_nms_v8_rotated if rotated else _L.lmi_nms_v8
+    check(fn(pred.data_ptr(), b, nc, nm, a, float(conf_thres), float(iou_thres), int(agnostic), int(max_det),
+             int(max_nms), float(max_wh), det.data_ptr(), count.data_ptr(), anchor.data_ptr(), ws.data_ptr(),
+             ws.numel(), _stream()))
     return det, count, anchor
+
+
+def finalize_obb(det: torch.Tensor, count: torch.Tensor, nc: int, model_hw: Tuple[int, int],
+                 orig_hw: Union[Tuple[int, int], torch.Tensor], thres: Union[float, torch.Tensor]):
+    """regularize_rboxes + scale_boxes(xywh=True) + xywhr2xyxyxyxy + per-class threshold on rotated NMS rows.
+    Returns dict(corners (B,max_det,4,2) fp32, keep (B,max_det) uint8, keep_count (B,)); det is not modified."""
+    _need_cuda(det, "det")
+    b, max_det, stride = det.shape
+    dev = det.device
+    corners = torch.empty((b, max_det, 4, 2), dtype=torch.float32, device=dev)
+    keep = torch.empty((b, max_det), dtype=torch.uint8, device=dev)
+    keep_count = torch.empty((b,), dtype=torch.int32, device=dev)
+    if isinstance(orig_hw, torch.Tensor):
+        _need_cuda(orig_hw, "orig_hw")
+        ohw = orig_hw.to(torch.int32).contiguous()
+        ohw_ptr, uh, uw = ohw.data_ptr(), 0, 0
+    else:
+        ohw_ptr, uh, uw = None, int(orig_hw[0]), int(orig_hw[1])
+    if isinstance(thres, torch.Tensor):
+        _need_cuda(thres, "thres")
+        th = thres.to(torch.float64).contiguous()
+        if th.numel() != nc:
+            raise ValueError("per-class thresholds must have nc entries")
+        th_ptr, ut = th.data_ptr(), 0.0
+    else:
+        th_ptr, ut = None, float(thres)
+    check(_L.lmi_finalize_obb(det.data_ptr(), count.data_ptr(), b, max_det, stride, nc, int(model_hw[0]), int(model_hw[1]),
+                              ohw_ptr, uh, uw, th_ptr, ut, corners.data_ptr(), keep.data_ptr(), keep_count.data_ptr(), _stream()))
+    return {"corners": corners, "keep": keep, "keep_count": keep_count}
 
 
 def finalize_detections(det: torch.Tensor, count: torch.Tensor, nc: int, model_hw: Tuple[int, int],

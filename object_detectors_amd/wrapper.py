@@ -443,3 +443,81 @@ class Yolov8PoseCore(Yolov8Core):
         results_dict['classes'] = classes
         time_info['postproc'] = time.time() - t0
         return results_dict, time_info
+
+
+class Yolov8ObbCore(Yolov8Core):
+    """Oriented-box models (object_detectors/yolov8_lmi/model.py:391-531; twin ultralytics_lmi/yolo/model.py).
+      postprocess :398-465 -> lmi_nms_v8_rotated + lmi_finalize_obb, one device->host copy
+      predict     :469-531 -> unchanged control flow; all corner points reverted in one call
+    Boxes are (n, 4, 2) corner points."""
+
+    @torch.inference_mode()
+    def postprocess(self, preds, img, orig_imgs, conf: Union[float, dict], iou=0.45, agnostic=False, max_det=300):
+        if not isinstance(preds, (torch.Tensor, list, tuple)):
+            self.logger.error(f'Prediction type {type(preds)} not supported expected torch.Tensor or list')
+            raise TypeError(f'Prediction type {type(preds)} not supported expected torch.Tensor or list')
+        if isinstance(preds, (list, tuple)):
+            preds = preds[0]
+        self._require_gpu('postprocess')
+        ops = _hip_ops()
+        nc = len(self.model.names)
+        conf2 = self.get_min_conf(conf)
+        thres = self._class_thresholds(conf)
+        preds = preds.to(self.device)
+        B = preds.shape[0]
+        model_hw = tuple(img.shape[2:])
+        shapes = [tuple((orig_imgs[i] if isinstance(orig_imgs, list) else orig_imgs).shape[:2]) for i in range(B)]
+        ohw = shapes[0] if all(s == shapes[0] for s in shapes) else torch.tensor(shapes, dtype=torch.int32, device=self.device)
+        det, count, _ = ops.nms_v8(preds, float(conf2), float(iou), agnostic=bool(agnostic), max_det=int(max_det), nc=nc, rotated=True)
+        fin = ops.finalize_obb(det, count, nc, model_hw, ohw, thres)
+        count_h = count.cpu().numpy()
+        keep_h = fin["keep"].cpu().numpy().astype(bool)
+        det_h = det[:, :, :6].cpu().numpy()
+        corners = fin["corners"]
+        corners_h = corners.cpu().numpy()
+        results = collections.defaultdict(list)
+        names = self.model.names
+        for i in range(B):
+            orig_img = orig_imgs[i] if isinstance(orig_imgs, list) else orig_imgs
+            n = int(count_h[i])
+            if n == 0:
+                continue
+            M = keep_h[i, :n]
+            classes = np.array([names[int(c)] for c in det_h[i, :n, 5]])
+            if isinstance(orig_img, torch.Tensor):
+                sel = torch.from_numpy(np.nonzero(M)[0]).to(det.device)
+                results['boxes'].append(corners[i, :n][sel])
+                results['scores'].append(det[i, :n, 4][sel])
+            else:
+                results['boxes'].append(corners_h[i, :n][M])
+                results['scores'].append(det_h[i, :n, 4][M])
+            results['classes'].append(classes[M].tolist())
+        return results
+
+    @torch.inference_mode()
+    def predict(self, image, configs, operators=[], iou=0.4, agnostic=False, max_det=300):
+        import gadget_utils.pipeline_utils as pipeline_utils
+        time_info = {}
+        t0 = time.time()
+        im = self.preprocess(image)
+        time_info['preproc'] = time.time() - t0
+        t0 = time.time()
+        pred = self.forward(im)
+        time_info['proc'] = time.time() - t0
+        t0 = time.time()
+        results = self.postprocess(pred, im, image, configs, iou, agnostic, max_det)
+        results_dict = collections.defaultdict(list)
+        if not len(results['boxes']):
+            time_info['postproc'] = time.time() - t0
+            return results_dict, time_info
+        boxes, scores, classes = results['boxes'][0], results['scores'][0], results['classes'][0]   # boxes [n_obj, 4, 2]
+        n = len(boxes)
+        if n:   # the 4n corner points in one call instead of one call per box (model.py:520-524)
+            flat = boxes.reshape(n * 4, 2)
+            flat = flat.contiguous() if isinstance(flat, torch.Tensor) else np.ascontiguousarray(flat)
+            boxes = pipeline_utils.revert_to_origin(flat, operators).reshape(n, 4, 2)
+        results_dict['boxes'] = boxes
+        results_dict['scores'] = scores
+        results_dict['classes'] = classes
+        time_info['postproc'] = time.time() - t0
+        return results_dict, time_info

@@ -1,0 +1,117 @@
+"""GPU parity for oriented-box models (reference object_detectors/yolov8_lmi/model.py:391-531,
+tests tests/object_detectors/yolov8_lmi/test_yolov8_model.py:213-256): lmi_nms_v8_rotated / lmi_finalize_obb against
+oracle/obb.py (PARITY UNPINNED against ultralytics itself), and the `Yolov8Obb` drop-in end to end.
+Kept indices are required to be identical whenever no decisive probiou lies within 2e-5 of the threshold (cos / sin /
+log / exp differ by an ulp between numpy and the GPU); the seeds below satisfy that and the tests assert it."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(ROOT, "object_detectors_amd", "dropin")
+if DROPIN not in sys.path:
+    sys.path.insert(0, DROPIN)
+
+from oracle import boxes as OB, geometry as OG, obb as OO  # noqa: E402
+from object_detectors_amd import synth  # noqa: E402
+from object_detectors_amd.nets.yolov8 import save_checkpoint  # noqa: E402
+
+F32 = np.float32
+NAMES = {0: "ship", 1: "plane", 2: "truck"}
+
+
+def obb_head(rng, B, nc, size, objects):
+    """synth.head with one extra channel, turned into an angle in [-pi/4, 3pi/4); clustered anchors share it."""
+    p = synth.head(rng, B, nc, 1, size, objects=objects)
+    p[:, -1] = (np.tanh(p[:, -1]) * 0.5 + 0.25) * math.pi
+    return p
+
+
+@pytest.mark.parametrize("agnostic", [False, True])
+@pytest.mark.parametrize("seed,nc,size,objects,max_det", [(1, 3, 320, 25, 300), (2, 80, 640, 60, 300), (3, 15, 640, 120, 40)])
+def test_rotated_nms_and_finalize(seed, nc, size, objects, max_det, agnostic):
+    from object_detectors_amd import hip_ops as ops
+    rng = np.random.default_rng(seed)
+    B = 4
+    p = obb_head(rng, B, nc, size, objects)
+    det, count, anchor = ops.nms_v8(torch.from_numpy(p).cuda(), 0.25, 0.45, agnostic=agnostic, max_det=max_det, nc=nc, rotated=True)
+    h0, w0 = 1080, 1920
+    thres = torch.tensor(rng.uniform(0.2, 0.6, nc), dtype=torch.float64).cuda()
+    fin = ops.finalize_obb(det, count, nc, (size, size), (h0, w0), thres)
+    torch.cuda.synchronize()
+    det_h, count_h, anchor_h = det.cpu().numpy(), count.cpu().numpy(), anchor.cpu().numpy()
+    corners, keep = fin["corners"].cpu().numpy(), fin["keep"].cpu().numpy().astype(bool)
+    ref = OO.non_max_suppression_rotated(p, 0.25, 0.45, agnostic=agnostic, max_det=max_det, nc=nc)
+    for b in range(B):
+        rows, ra, margin = ref[b]
+        assert margin > 2e-5, "seed puts a decision on the threshold: pick another"
+        n = int(count_h[b])
+        assert anchor_h[b, :n].tolist() == ra.tolist()
+        assert np.array_equal(det_h[b, :n], rows)                        # rows are copies of head values: bit-exact
+        rc = OO.postprocess_obb(rows, (size, size), (h0, w0, 3))
+        assert np.abs(corners[b, :n] - rc).max() <= 1e-3                  # boxes within 1e-3 px
+        M = OB.class_filter(rows[:, 4], rows[:, 5], thres.cpu().numpy())
+        assert keep[b, :n].tolist() == M.tolist() and int(fin["keep_count"][b]) == int(M.sum())
+    assert count_h.max() <= max_det and (count_h.max() == max_det or max_det == 300)
+
+
+def test_rotated_nms_not_greedy_and_errors():
+    from object_detectors_amd import hip_ops as ops
+    # A-B-C chain: greedy would keep A and C, nms_rotated keeps A only
+    boxes = np.array([[100, 100, 80, 20, 0.0], [130, 100, 80, 20, 0.0], [160, 100, 80, 20, 0.0]], F32)
+    iou = OO.batch_probiou(boxes, boxes)
+    thr = float((iou[0, 2] + iou[0, 1]) / 2)
+    p = np.zeros((1, 4 + 1 + 1, 64), F32)
+    p[0, :4, :3] = boxes[:, :4].T
+    p[0, 4, :3] = [0.9, 0.8, 0.7]
+    det, count, anchor = ops.nms_v8(torch.from_numpy(p).cuda(), 0.5, thr, nc=1, rotated=True)
+    assert count.item() == 1 and anchor[0, 0].item() == 0
+    det, count, anchor = ops.nms_v8(torch.from_numpy(p).cuda(), 0.5, 0.999999, nc=1, rotated=True)
+    assert count.item() == 3 and anchor[0, :3].tolist() == [0, 1, 2]
+    with pytest.raises(ValueError):
+        ops.nms_v8(torch.zeros((1, 5, 64), device="cuda"), 0.5, 0.45, nc=1, rotated=True)   # no angle channel
+
+
+@pytest.fixture(scope="module")
+def obb(tmp_path_factory):
+    from object_detector import ObjectDetector
+    import od_models  # noqa: F401
+    from yolov8_lmi.model import Yolov8Obb
+    path = str(tmp_path_factory.mktemp("o") / "obb.pt")
+    save_checkpoint(path, "n", len(NAMES), names=NAMES, seed=5, task="obb")
+    m = ObjectDetector(metadata=dict(version='v0', model_name='yolov8', task='obb', framework='ultralytics'), weights=path)
+    assert isinstance(m, Yolov8Obb) and m.device.type == "cuda"
+    for conv in m.model.head.cv3:
+        conv[-1].bias.data.normal_(-2.0, 0.5)
+        conv[-1].weight.data.mul_(8.0)
+    return m
+
+
+def test_obb_predict_against_oracle(obb):
+    rng = np.random.default_rng(9)
+    frame = synth.frames_u8(rng, 1, 256, 256)[0]
+    operators = [{"resize": [256, 144, 640, 360]}, {"pad": [0, 0, 56, 56]}]
+    im = obb.preprocess(frame)
+    pred = obb.forward(im)[0].cpu().numpy()
+    s = pred[0, 4:4 + len(NAMES)].max(0)
+    conf = float((s.min() + 3 * s.max()) / 4)
+    (rows, ra, margin), = OO.non_max_suppression_rotated(pred, conf, 0.4, nc=len(NAMES), max_det=50)
+    assert len(rows) > 0 and margin > 2e-5
+    rc = OO.postprocess_obb(rows, (256, 256), (256, 256, 3))
+    ref = OG.revert_to_origin(rc.reshape(-1, 2), operators).reshape(-1, 4, 2)
+    for as_tensor in (False, True):
+        image = torch.from_numpy(frame).cuda() if as_tensor else frame
+        out, tinfo = obb.predict(image, conf, operators=operators, iou=0.4, max_det=50)
+        bx = out['boxes'].cpu().numpy() if as_tensor else out['boxes']
+        assert bx.shape == ref.shape and np.abs(bx - ref).max() <= 1      # rounded pixels: an ulp before rounding may flip one
+        assert (bx != ref).mean() < 0.01
+        assert out['classes'] == [NAMES[int(c)] for c in rows[:, 5]]
+        assert np.array_equal(out['scores'].cpu().numpy() if as_tensor else out['scores'], rows[:, 4])
+    none, _ = obb.predict(frame, 0.9999999, operators=operators)
+    assert len(none['boxes']) == 0
