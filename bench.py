@@ -140,7 +140,12 @@ def main():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per step in the timed region "
                     "(the per-kernel roofline timing then comes from an eager, event-timed pass right after it)")
+    ap.add_argument("--mask-logits", default="rows", choices=["rows", "mfma"],
+                    help="coefficient x prototype product: row-sparse vector-ALU kernel (default) or dense fp32 MFMA tiles "
+                         "(measurement of the MFMA variant; sets LMI_MASK_LOGITS for liblmi_hip)")
     args = ap.parse_args()
+    if args.mask_logits == "mfma":
+        os.environ["LMI_MASK_LOGITS"] = "mfma"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -228,9 +233,20 @@ def main():
         with open(tpath) as f:
             tk = json.load(f).get("kernels", {})
         traffic = tk.get(kernel.split("<")[0], {}).get("traffic")
+    # measured device-to-device copy bandwidth on this box (read + write bytes), quoted beside the spec peak
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    ce = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    for a, b in ce:
+        a.record(); dst.copy_(src); b.record()
+    torch.cuda.synchronize()
+    copy_gbs = 2 * src.numel() / (sorted(a.elapsed_time(b) for a, b in ce)[2] * 1e-3) / 1e9
+    del src, dst
     roof = {"kernel": kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_ms": round(ms, 4),
-            "algorithmic_bytes_per_launch": int(alg)}
+            "algorithmic_bytes_per_launch": int(alg), "measured_copy_GBs": round(copy_gbs, 1),
+            "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
 
     res = None
     if rank == 0:
@@ -249,7 +265,7 @@ def main():
             "config": {"workload": cfg["desc"], "name": args.workload, "per_gpu_batch": B, "conf": CONF, "iou": IOU,
                        "max_det": MAX_DET, "survivors_per_batch": n_surv, "nms_kept_per_batch": n_kept,
                        "per_rank": [{"images": int(r["images"]), "survivors": int(r["survivors"]), "kept_checksum": (int(r["chk_hi"]) << 31) | int(r["chk_lo"])} for r in reports],
-                       "mask_dtype": "uint8", "forward": "excluded", "launch": "hip graph replay" if args.graph else "eager", "sharding": f"{world} x independent batches, no collective on the hot path"},
+                       "mask_dtype": "uint8", "forward": "excluded", "launch": "hip graph replay" if args.graph else "eager", "mask_logits": args.mask_logits, "sharding": f"{world} x independent batches, no collective on the hot path"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(res), flush=True)

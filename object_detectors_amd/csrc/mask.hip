@@ -14,6 +14,9 @@
 //                        strip needs in LDS, then bilinear (align_corners=False) -> box crop ->
 //                        `> 0`, 16 bytes per lane per store.  HBM-write-bound: m*H0*W0 bytes of
 //                        uint8 per image are written exactly once (zeros outside the box included).
+#include <cstdlib>
+#include <cstring>
+
 #include "common.h"
 
 namespace {
@@ -432,17 +435,22 @@ int lmi_mask_logits(const float *proto, int batch, int nm, int mh, int mw, const
   G.proto = proto; G.det = det; G.slot_map = slot_map; G.slot_base = slot_base; G.logits = reinterpret_cast<float *>(workspace);
   G.batch = batch; G.max_det = max_det; G.det_stride = det_stride; G.capacity = capacity_masks; G.g = g;
   const int npx = (g.bottom - g.top) * mw;
-  if ((mw % 2) == 0 && lmi_is_aligned(proto, 8)) {
+  // LMI_MASK_LOGITS=mfma selects the dense MFMA tiles for every shape (a measurement knob: bench.py --mask-logits mfma)
+  const char *mode = getenv("LMI_MASK_LOGITS");
+  const bool force_mfma = mode && strcmp(mode, "mfma") == 0;
+  if (!force_mfma && (mw % 2) == 0 && lmi_is_aligned(proto, 8)) {
     const int tiles = (npx + 127) / 128;
     hipLaunchKernelGGL(mask_logits_rows_kernel, dim3((tiles + 3) / 4, batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
     return lmi_check_launch("mask_logits_rows_kernel");
   }
-  // odd prototype width: dense MFMA tiles, one pixel per lane
-  const int ntiles = (npx + 31) / 32;
-  G.tiles_per_block = 4;
+  // dense MFMA tiles: 4 adjacent pixels per lane when rows are whole 16-byte vectors, else one pixel per lane
+  const bool vec4 = (mw % 4) == 0 && lmi_is_aligned(proto, 16);
+  const int ntiles = (npx + (vec4 ? 127 : 31)) / (vec4 ? 128 : 32);
+  G.tiles_per_block = vec4 ? 1 : 4;
   const int gx = (ntiles + 4 * G.tiles_per_block - 1) / (4 * G.tiles_per_block);
   dim3 ggrid(gx, (max_det + 31) / 32, batch);
-  hipLaunchKernelGGL(mask_gemm_kernel<1>, ggrid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
+  if (vec4) hipLaunchKernelGGL(mask_gemm_kernel<4>, ggrid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
+  else hipLaunchKernelGGL(mask_gemm_kernel<1>, ggrid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
   return lmi_check_launch("mask_gemm_kernel");
 }
 
