@@ -239,9 +239,20 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
     if (row >= 0) {
       const uint32_t goff = (uint32_t)((long long)row * stride + span_b0);
       const uint32_t aligned = goff & ~15u;
-      for (int ch = tid % LPS; ch < nchunk; ch += LPS) {
-        auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, aligned + 16u * ch, 0, 0);
-        *reinterpret_cast<decltype(v) *>(rows + slot * P.pitch + 16 * ch) = v;
+      // four loads in flight per lane before the first LDS write: the loop is latency-bound otherwise (4K frames
+      // need 9 chunks per lane).  Loads past the row's span get an out-of-range offset (dropped by the range check, no
+      // traffic) and their LDS writes are skipped.
+      for (int ch = tid % LPS; ch < nchunk; ch += 4 * LPS) {
+        auto v0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, aligned + 16u * ch, 0, 0);
+        constexpr uint32_t kOut = 0xfffffff0u;  // beyond num_records: the load is dropped without touching memory
+        auto v1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ch + LPS < nchunk ? aligned + 16u * (ch + LPS) : kOut, 0, 0);
+        auto v2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ch + 2 * LPS < nchunk ? aligned + 16u * (ch + 2 * LPS) : kOut, 0, 0);
+        auto v3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ch + 3 * LPS < nchunk ? aligned + 16u * (ch + 3 * LPS) : kOut, 0, 0);
+        unsigned char *q = rows + slot * P.pitch + 16 * ch;
+        *reinterpret_cast<decltype(v0) *>(q) = v0;
+        if (ch + LPS < nchunk) *reinterpret_cast<decltype(v0) *>(q + 16 * LPS) = v1;
+        if (ch + 2 * LPS < nchunk) *reinterpret_cast<decltype(v0) *>(q + 32 * LPS) = v2;
+        if (ch + 3 * LPS < nchunk) *reinterpret_cast<decltype(v0) *>(q + 48 * LPS) = v3;
       }
     }
   }
