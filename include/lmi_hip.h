@@ -272,6 +272,18 @@ int lmi_revert_masks_stage(const void *src, int dtype, int64_t m, int src_h, int
                            int fit_w, int resize_h, int resize_w, int flip_lr, int flip_ud,
                            void *dst, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Mask paste -- replaces `rescale_masks(masks, boxes, image_shape, threshold)`
+ * (lmi_utils/postprocess_utils/mask_utils.py:66-140, used by detectron2_lmi/model.py:257,489): N soft
+ * masks (n, mask_h, mask_w) fp32 are sampled into their boxes (x0,y0,x1,y1 = first four floats of each
+ * `box_stride`-float row) over the whole (img_h, img_w) image with aten's bilinear grid_sample
+ * (align_corners=False, zero padding) and thresholded with `>=`; out [device] uint8 (n, img_h, img_w) of
+ * 0/1 (the reference returns bool).  One launch for all masks, no (n, H, W) fp32 intermediate.
+ */
+int lmi_paste_masks(const float *masks, int64_t n, int mask_h, int mask_w, const float *boxes,
+                    int box_stride, int img_h, int img_w, float threshold, uint8_t *out,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -158,6 +158,62 @@ __global__ __launch_bounds__(256) void revert_masks_kernel(MaskStage S) {
   }
 }
 
+// rescale_masks (lmi_utils/postprocess_utils/mask_utils.py:12-140): paste N soft masks of a
+// fixed resolution (e.g. 28x28) into their boxes of an (H, W) image and threshold.  Per output pixel, the
+// reference's arithmetic: g = ((p + 0.5) - lo) / (hi - lo) * 2 - 1, aten grid_sample (bilinear, zero padding,
+// align_corners=False): i = ((g + 1) * size - 1) / 2, taps floor(i), floor(i)+1 weighted (1-f), f, out-of-range
+// taps contribute 0; `>= threshold`.  Pixels whose taps all fall outside the mask are zero without reading it.
+// grid: x = 16-pixel column chunks in groups of 64 lanes, y = rows / 4, z = mask.  One 16-byte store per lane.
+struct PasteParams {
+  const float *masks;   // (n, hm, wm)
+  const float *boxes;   // (n, box_stride) x0,y0,x1,y1 first
+  uint8_t *out;         // (n, H, W) 0/1
+  int hm, wm, box_stride, H, W;
+  float threshold;
+};
+
+__global__ __launch_bounds__(256) void paste_masks_kernel(PasteParams P) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int y = blockIdx.y * 4 + wave;
+  const int xq = (blockIdx.x * 64 + lane) * 16;
+  if (y >= P.H || xq >= P.W) return;
+  const int i = blockIdx.z;
+  const float *b = P.boxes + (size_t)i * P.box_stride;
+  const float bx0 = b[0], by0 = b[1], bx1 = b[2], by1 = b[3];
+  const float *m = P.masks + (size_t)i * P.hm * P.wm;
+  uint8_t *o = P.out + ((size_t)i * P.H + y) * P.W + xq;
+
+  const float gy = (((float)y + 0.5f) - by0) / (by1 - by0) * 2.0f - 1.0f;
+  const float fy = ((gy + 1.0f) * (float)P.hm - 1.0f) / 2.0f;
+  const float fy0 = floorf(fy);
+  const float wy1 = fy - fy0, wy0 = 1.0f - wy1;
+  const int iy0 = (int)fmaxf(fminf(fy0, 1.0e9f), -1.0e9f);
+  const bool r0 = iy0 >= 0 && iy0 < P.hm, r1 = iy0 + 1 >= 0 && iy0 + 1 < P.hm;
+
+  uint8_t v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int x = xq + k;
+    const float gx = (((float)x + 0.5f) - bx0) / (bx1 - bx0) * 2.0f - 1.0f;
+    const float fx = ((gx + 1.0f) * (float)P.wm - 1.0f) / 2.0f;
+    const float fx0 = floorf(fx);
+    const float wx1 = fx - fx0, wx0 = 1.0f - wx1;
+    const int ix0 = (int)fmaxf(fminf(fx0, 1.0e9f), -1.0e9f);
+    const bool c0 = ix0 >= 0 && ix0 < P.wm, c1 = ix0 + 1 >= 0 && ix0 + 1 < P.wm;
+    float acc = 0.0f;
+    if (r0 && c0) acc += m[iy0 * P.wm + ix0] * (wy0 * wx0);
+    if (r0 && c1) acc += m[iy0 * P.wm + ix0 + 1] * (wy0 * wx1);
+    if (r1 && c0) acc += m[(iy0 + 1) * P.wm + ix0] * (wy1 * wx0);
+    if (r1 && c1) acc += m[(iy0 + 1) * P.wm + ix0 + 1] * (wy1 * wx1);
+    v[k] = acc >= P.threshold ? 1 : 0;   // NaN (degenerate box) compares false, like torch
+  }
+  if (xq + 16 <= P.W && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+    Px<uint8_t>::store(o, v);
+  } else {
+    for (int k = 0; k < 16 && xq + k < P.W; ++k) o[k] = v[k];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -206,6 +262,22 @@ int lmi_revert_masks_stage(const void *src, int dtype, int64_t m, int src_h, int
   if (dtype == LMI_F32) hipLaunchKernelGGL(revert_masks_kernel<float>, grid, dim3(256), 0, s, S);
   else hipLaunchKernelGGL(revert_masks_kernel<uint8_t>, grid, dim3(256), 0, s, S);
   return lmi_check_launch("revert_masks_kernel");
+}
+
+int lmi_paste_masks(const float *masks, int64_t n, int mask_h, int mask_w, const float *boxes, int box_stride, int img_h,
+                    int img_w, float threshold, uint8_t *out, void *stream) {
+  LMI_REQUIRE(n >= 0 && n <= 65535, LMI_ERR_LIMIT, "lmi_paste_masks: %lld masks not in 0..65535", (long long)n);
+  LMI_REQUIRE(mask_h > 0 && mask_w > 0 && img_h > 0 && img_w > 0 && box_stride >= 4, LMI_ERR_BAD_ARG,
+              "lmi_paste_masks: bad shape mask=%dx%d image=%dx%d box_stride=%d", mask_h, mask_w, img_h, img_w, box_stride);
+  if (n == 0) return LMI_OK;
+  LMI_REQUIRE(masks && boxes && out, LMI_ERR_BAD_ARG, "lmi_paste_masks: NULL pointer");
+  PasteParams P;
+  P.masks = masks; P.boxes = boxes; P.out = out; P.hm = mask_h; P.wm = mask_w; P.box_stride = box_stride;
+  P.H = img_h; P.W = img_w; P.threshold = threshold;
+  dim3 grid(((img_w + 15) / 16 + 63) / 64, (img_h + 3) / 4, (unsigned)n);
+  LMI_REQUIRE(grid.y <= 65535, LMI_ERR_LIMIT, "lmi_paste_masks: image height %d too large", img_h);
+  hipLaunchKernelGGL(paste_masks_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), P);
+  return lmi_check_launch("paste_masks_kernel");
 }
 
 }  // extern "C"

@@ -395,3 +395,26 @@ def revert_masks(masks: torch.Tensor, operations: Sequence[dict]) -> torch.Tenso
                                         1 if lr else 0, 1 if ud else 0, out.data_ptr(), _stream()))
         cur = out
     return cur
+
+
+def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, image_shape: Tuple[int, int], threshold: float = 0.5) -> torch.Tensor:
+    """`rescale_masks` (lmi_utils/postprocess_utils/mask_utils.py:66-140): (N,Hm,Wm) soft masks pasted into their xyxy
+    boxes of an (H,W) image, `>= threshold`.  Returns a bool tensor (N,H,W) like the reference."""
+    _need_cuda(masks, "masks")
+    _need_cuda(boxes, "boxes")
+    if masks.ndim != 3 or masks.shape[-1] != masks.shape[-2]:
+        raise AssertionError("Only square mask predictions are supported")
+    n = masks.shape[0]
+    if boxes.shape[0] != n:
+        raise AssertionError(tuple(boxes.shape))
+    h, w = int(image_shape[0]), int(image_shape[1])
+    out = torch.empty((n, h, w), dtype=torch.uint8, device=masks.device)
+    if n == 0:
+        return out.bool()
+    if threshold < 0:
+        raise ValueError("paste_masks: the visualisation mode (threshold < 0, soft uint8 output) is not provided")
+    m = masks.float().contiguous()
+    b = boxes.float().contiguous()
+    check(_L.lmi_paste_masks(m.data_ptr(), n, m.shape[1], m.shape[2], b.data_ptr(), b.shape[1], h, w, float(threshold),
+                             out.data_ptr(), _stream()))
+    return out.view(torch.bool)

@@ -1,0 +1,73 @@
+"""GPU parity for the mask paste (lmi_utils/postprocess_utils/mask_utils.py:66-140):
+lmi_paste_masks against torch-CPU executing the reference's op sequence with its own F.grid_sample
+(oracle/paste.py; PARITY UNPINNED against the reference module itself, which needs numba + cv2 to import)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(ROOT, "object_detectors_amd", "dropin")
+if DROPIN not in sys.path:
+    sys.path.insert(0, DROPIN)
+
+from oracle import masks as OM, paste as OP  # noqa: E402
+
+F32 = np.float32
+
+
+def soft_masks(rng, n, s):
+    y, x = np.mgrid[0:s, 0:s]
+    out = np.empty((n, s, s), F32)
+    for i in range(n):
+        cy, cx, r = rng.uniform(s * 0.3, s * 0.7), rng.uniform(s * 0.3, s * 0.7), rng.uniform(s * 0.2, s * 0.5)
+        d = np.sqrt((y - cy) ** 2 + (x - cx) ** 2)
+        out[i] = 1.0 / (1.0 + np.exp((d - r) * 1.5)) + rng.normal(0, 0.02, (s, s))
+    return np.clip(out, 0, 1).astype(F32)
+
+
+@pytest.mark.parametrize("n,s,h,w", [(7, 28, 480, 640), (3, 28, 101, 67), (40, 28, 1080, 1920), (2, 14, 64, 64)])
+def test_paste_masks_vs_torch_grid_sample(n, s, h, w):
+    from postprocess_utils.mask_utils import rescale_masks
+    rng = np.random.default_rng(n * 7 + s)
+    m = soft_masks(rng, n, s)
+    x0, y0 = rng.uniform(-20, w * 0.6, n), rng.uniform(-20, h * 0.6, n)
+    b = np.stack([x0, y0, x0 + rng.uniform(8, w * 0.5, n), y0 + rng.uniform(8, h * 0.5, n)], 1).astype(F32)   # some boxes leave the image
+    got = rescale_masks(torch.from_numpy(m).cuda(), torch.from_numpy(b).cuda(), (h, w), 0.5)
+    assert got.dtype == torch.bool and got.shape == (n, h, w)
+    got = got.cpu().numpy()
+    k = min(n, 6)                                   # the CPU oracle samples whole images: a few masks are enough
+    ref = OP.rescale_masks(m[:k], b[:k], (h, w), 0.5)
+    assert ref.sum() > 0 and OM.mask_iou(got[:k], ref) >= 0.999
+    assert (got[:k] != ref).mean() < 1e-5           # only pixels whose sampled value sits on the threshold may differ
+    # nothing outside the box grown by one mask texel (zero padding of grid_sample)
+    for i in range(n):
+        tx, ty = (b[i, 2] - b[i, 0]) / s, (b[i, 3] - b[i, 1]) / s
+        ys, xs = np.nonzero(got[i])
+        if len(ys):
+            assert xs.min() + 0.5 >= b[i, 0] - tx and xs.max() + 0.5 <= b[i, 2] + tx
+            assert ys.min() + 0.5 >= b[i, 1] - ty and ys.max() + 0.5 <= b[i, 3] + ty
+    # batch invariance
+    one = rescale_masks(torch.from_numpy(m[1:2]).cuda(), torch.from_numpy(b[1:2]).cuda(), (h, w), 0.5)
+    assert np.array_equal(one[0].cpu().numpy(), got[1])
+
+
+def test_paste_masks_edges():
+    from postprocess_utils.mask_utils import rescale_masks
+    empty = rescale_masks(torch.zeros((0, 28, 28), device="cuda"), torch.zeros((0, 4), device="cuda"), (50, 60))
+    assert empty.shape == (0, 50, 60)
+    with pytest.raises(AssertionError):
+        rescale_masks(torch.zeros((1, 28, 20), device="cuda"), torch.zeros((1, 4), device="cuda"), (50, 60))
+    with pytest.raises(RuntimeError):
+        rescale_masks(torch.zeros((1, 28, 28)), torch.zeros((1, 4)), (50, 60))
+    # a mask of ones fills its box interior; a degenerate (zero-width) box yields nothing (0/0 -> NaN >= thr is False)
+    m = torch.ones((2, 28, 28), device="cuda")
+    b = torch.tensor([[10.0, 5.0, 30.0, 25.0], [40.0, 5.0, 40.0, 25.0]], device="cuda")
+    out = rescale_masks(m, b, (40, 60), 0.5).cpu().numpy()
+    assert out[0, 6:24, 11:29].all() and out[0].sum() <= 22 * 22 and out[1].sum() == 0
+    ref = OP.rescale_masks(m.cpu().numpy(), b.cpu().numpy(), (40, 60), 0.5)
+    assert np.array_equal(out, ref)
