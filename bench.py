@@ -38,6 +38,8 @@ WORKLOADS = {
                     desc="YOLOv8x-seg 1280 bs32, synthetic 1080p frames, head (32,116,33600), proto (32,32,320,320)"),
     "det640_4k": dict(batch=64, h=2160, w=3840, size=640, nc=80, nm=0, objects=40,
                       desc="YOLOv8m detect 640, synthetic 4K frames, 64 per step per GPU"),
+    "seg640_dense": dict(batch=16, h=1080, w=1920, size=640, nc=80, nm=32, objects=110, cluster=(8, 16),
+                         desc="YOLOv8l-seg 640 dense scenes (>= 1000 candidates per image), 16 per step per GPU, head (16,116,8400)"),
 }
 CONF, IOU, MAX_DET, MASK_CONF = 0.25, 0.45, 300, 0.25
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
@@ -53,7 +55,8 @@ def make_inputs(cfg, seed, device):
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     frames = torch.randint(0, 256, (cfg["batch"], cfg["h"], cfg["w"], 3), dtype=torch.uint8, device=device, generator=g)
-    head = torch.from_numpy(synth.head(rng, cfg["batch"], cfg["nc"], cfg["nm"], cfg["size"], cfg["objects"])).to(device)
+    head = torch.from_numpy(synth.head(rng, cfg["batch"], cfg["nc"], cfg["nm"], cfg["size"], cfg["objects"],
+                                       cluster=cfg.get("cluster", (5, 16)))).to(device)
     proto = None
     if cfg["nm"]:
         proto = torch.from_numpy(synth.proto(rng, cfg["batch"], cfg["nm"], cfg["size"] // 4, cfg["size"] // 4)).to(device)

@@ -270,9 +270,20 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
     const float carea = (cb.z - cb.x) * (cb.w - cb.y);
 
     // A: chunk vs kept boxes, kept index strided over the 16 waves
+    // four kept boxes per iteration, no short-circuit: the 20 LDS broadcasts are issued together instead of one
+    // dependent round trip per kept box
     bool hit = false;
-    for (int k = wave; k < K; k += kSortThreads / 64)
-      hit = hit || iou_gt(kx1[k], ky1[k], kx2[k], ky2[k], karea[k], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
+    constexpr int NW = kSortThreads / 64;
+    int k = wave;
+    for (; k + 3 * NW < K; k += 4 * NW) {
+      const bool h0 = iou_gt(kx1[k], ky1[k], kx2[k], ky2[k], karea[k], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
+      const bool h1 = iou_gt(kx1[k + NW], ky1[k + NW], kx2[k + NW], ky2[k + NW], karea[k + NW], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
+      const bool h2 = iou_gt(kx1[k + 2 * NW], ky1[k + 2 * NW], kx2[k + 2 * NW], ky2[k + 2 * NW], karea[k + 2 * NW], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
+      const bool h3 = iou_gt(kx1[k + 3 * NW], ky1[k + 3 * NW], kx2[k + 3 * NW], ky2[k + 3 * NW], karea[k + 3 * NW], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
+      hit = hit | h0 | h1 | h2 | h3;
+    }
+    for (; k < K; k += NW)
+      hit = hit | iou_gt(kx1[k], ky1[k], kx2[k], ky2[k], karea[k], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
     if (hit && lane < m) supp[lane] = 1;
 
     // B: pair masks inside the chunk: row j = lanes i > j that j would suppress
