@@ -46,9 +46,10 @@ def per_launch(prof_dir, sub, counter):
     files = glob.glob(os.path.join(prof_dir, sub, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         raise SystemExit(f"no counter csv under {prof_dir}/{sub}")
+    newest = max(files, key=os.path.getmtime)   # gpurun_out keeps earlier runs' files beside the new one
     by_dispatch = collections.defaultdict(float)
     names = {}
-    for row in csv.DictReader(open(files[0])):
+    for row in csv.DictReader(open(newest)):
         if row["Counter_Name"] != counter:
             continue
         key = row["Dispatch_Id"]
