@@ -284,6 +284,29 @@ int lmi_paste_masks(const float *masks, int64_t n, int mask_h, int mask_w, const
                     int box_stride, int img_h, int img_w, float threshold, uint8_t *out,
                     void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Segments -- replaces `ops.masks2segments(masks)`
+ * (object_detectors/yolov8_lmi/model.py:238-243; yolov5_trt.py:418-431: cv2.findContours with
+ * RETR_EXTERNAL, CHAIN_APPROX_SIMPLE on masks copied to the host).
+ * lmi_pack_mask_boxes [device]: masks (m, img_h, img_w) of LMI_U8 or LMI_F32; boxes int32 (m,4)
+ *   x0,y0,x1,y1 half-open pixel ranges inside the image (a mask must be zero outside its range);
+ *   writes, for mask i, (y1-y0) rows of ceil((x1-x0)/64) 64-bit words (bit c of word w = pixel
+ *   x0 + 64w + c != 0) starting at out_words[word_offset[i]].  All pointers are device pointers.
+ * lmi_trace_contours_host [host, no GPU work]: border following (Suzuki-Abe outer borders of the
+ *   hole-filled 8-connected components, collinear runs collapsed) on the packed rows copied to the
+ *   host, `threads` worker threads over the masks.  strategy_all != 0: every external contour of a
+ *   mask back to back; 0: the longest one.  Points (x, y) in image coordinates go to out_xy
+ *   (capacity_points pairs), mask after mask, points_per_mask[i] of them for mask i.  Returns the
+ *   total number of points; if that exceeds capacity_points nothing is written (call again with a
+ *   larger buffer); negative = error status.
+ */
+int lmi_pack_mask_boxes(const void *masks, int dtype, int64_t m, int img_h, int img_w,
+                        const int32_t *boxes, const int64_t *word_offset, uint64_t *out_words,
+                        void *stream);
+int64_t lmi_trace_contours_host(const uint64_t *words, int64_t m, const int32_t *boxes,
+                                const int64_t *word_offset, int strategy_all, int threads,
+                                int32_t *out_xy, int64_t capacity_points, int64_t *points_per_mask);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,9 @@ SIGNATURES = {
                                    C.c_void_p, C.c_int64, C.c_void_p]),
     "lmi_paste_masks": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                   C.c_void_p, C.c_void_p]),
+    "lmi_pack_mask_boxes": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lmi_trace_contours_host": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                            C.c_void_p]),
     "lmi_revert_points_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "lmi_revert_masks_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

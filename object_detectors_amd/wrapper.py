@@ -250,8 +250,8 @@ class Yolov8Core:
                 if masks is None:
                     masks = torch.zeros((0,) + tuple(orig_img.shape[:2]), dtype=self.mask_dtype, device=self.device)
                 results['masks'].append(masks if (return_tensor or masks_on_device) else masks.cpu().numpy())
-                if return_segments:
-                    segments = masks2segments(masks)
+                if return_segments:   # bit-packed box regions are copied to the host, contours traced there in C++
+                    segments = masks2segments(masks, boxes=det_h[i, :n, :4][M] if len(masks) == int(M.sum()) else None)
                     if return_tensor:
                         segments = [self.from_numpy(x) for x in segments]
                     results['segments'].append(segments)

@@ -22,7 +22,8 @@ import od_models  # noqa: E402,F401
 from yolov8_lmi.model import Yolov8  # noqa: E402
 from ultralytics_lmi.yolo.model import Yolo  # noqa: E402
 from object_detectors_amd.nets.yolov8 import save_checkpoint  # noqa: E402
-from object_detectors_amd import segments as SG  # noqa: E402
+from oracle import segments as SG  # noqa: E402
+from object_detectors_amd import segments as PSG  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -154,3 +155,49 @@ def test_external_contours():
     d = np.eye(5, dtype=np.uint8)
     (c,) = SG.find_external_contours(d)
     assert c[0].tolist() == [0, 0] and [4, 4] in c.tolist()
+
+
+def test_contour_tracer_matches_oracle_on_host_arrays():
+    """The product's C++ tracer (packed bits, object_detectors_amd/csrc/contours.hip) against the numpy/scipy oracle,
+    point for point: hand cases, random blobs, thin structures, nested components, both strategies, with and
+    without box hints."""
+    rng = np.random.default_rng(12)
+    h, w = 70, 150
+    yy, xx = np.mgrid[0:h, 0:w]
+    masks = []
+    m = np.zeros((h, w), np.uint8); m[2:7, 3:9] = 1; m[3:6, 4:8] = 0; m[4, 5] = 1; m[9, 11] = 1
+    masks.append(m)
+    masks.append(np.zeros((h, w), np.uint8))
+    d = np.zeros((h, w), np.uint8); d[np.arange(40), np.arange(40) + 70] = 1      # diagonal line crossing a word boundary
+    masks.append(d)
+    for _ in range(8):                                                             # unions of ellipses, some touching the border
+        m = np.zeros((h, w), bool)
+        for _ in range(int(rng.integers(1, 5))):
+            cy, cx, ry, rx = rng.uniform(0, h), rng.uniform(0, w), rng.uniform(2, 25), rng.uniform(2, 50)
+            m |= ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1
+        masks.append(m.astype(np.uint8))
+    masks.append((rng.random((h, w)) < 0.5).astype(np.uint8))                      # salt and pepper: many tiny components
+    ring = (((yy - 35) / 30.0) ** 2 + ((xx - 75) / 60.0) ** 2 < 1) & ~(((yy - 35) / 24.0) ** 2 + ((xx - 75) / 50.0) ** 2 < 1)
+    ring |= ((yy - 35) ** 2 + (xx - 75) ** 2 < 30)                                 # a blob inside the ring's hole: not external
+    masks.append(ring.astype(np.uint8))
+    full = np.ones((h, w), np.uint8)
+    masks.append(full)
+    stack = np.stack(masks)
+    for strategy in ("all", "largest"):
+        ref = SG.masks2segments(stack, strategy=strategy)
+        got = PSG.masks2segments(stack, strategy=strategy, threads=3)
+        assert len(got) == len(ref)
+        for g, r in zip(got, ref):
+            assert g.dtype == np.float32 and g.shape == r.shape and np.array_equal(g, r)
+    # box hints: any box that contains the mask's pixels gives the same points
+    boxes = np.array([[0, 0, w, h]] * len(masks), np.float32)
+    ys, xs = np.nonzero(masks[3])
+    boxes[3] = [xs.min() - 0.5, ys.min() - 0.3, xs.max() + 0.2, ys.max() + 0.9]
+    got = PSG.masks2segments(stack, boxes=boxes)
+    for g, r in zip(got, SG.masks2segments(stack)):
+        assert np.array_equal(g, r)
+    assert PSG.masks2segments(stack[:0]) == []
+    # float and torch CPU inputs
+    got = PSG.masks2segments(torch.from_numpy(stack[:4].astype(np.float32)))
+    for g, r in zip(got, SG.masks2segments(stack[:4])):
+        assert np.array_equal(g, r)

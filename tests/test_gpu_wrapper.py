@@ -163,3 +163,34 @@ def test_predict_seg_with_operators_reverts_on_device(models):
             assert s.shape[1] == 2 and (s >= 0).all() and (s == np.round(s)).all()
             if len(s):
                 assert s[:, 0].max() <= 640 and s[:, 1].max() <= 360 + 140   # contour points of the padded canvas, un-padded then un-resized
+
+
+def test_segments_from_device_masks_match_oracle():
+    """masks2segments on GPU masks (bit-packed box regions -> host C++ tracer) against the numpy/scipy oracle run on
+    the same masks copied whole, uint8 and fp32, with and without box hints."""
+    from oracle import segments as OS
+    from object_detectors_amd import segments as PSG
+    rng = np.random.default_rng(31)
+    n, h, w = 9, 270, 480
+    yy, xx = np.mgrid[0:h, 0:w]
+    masks = np.zeros((n, h, w), np.uint8)
+    boxes = np.zeros((n, 4), np.float32)
+    for i in range(n):
+        x0, y0 = rng.uniform(0, w * 0.6), rng.uniform(0, h * 0.6)
+        x1, y1 = min(x0 + rng.uniform(20, w * 0.5), w), min(y0 + rng.uniform(20, h * 0.5), h)
+        boxes[i] = [x0, y0, x1, y1]
+        m = np.zeros((h, w), bool)
+        for _ in range(3):
+            cy, cx, ry, rx = rng.uniform(y0, y1), rng.uniform(x0, x1), rng.uniform(4, 60), rng.uniform(4, 90)
+            m |= ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1
+        m &= (xx >= x0) & (xx < x1) & (yy >= y0) & (yy < y1)          # what crop_mask leaves
+        masks[i] = m
+    ref = OS.masks2segments(masks)
+    for dt in (torch.uint8, torch.float32):
+        dm = torch.from_numpy(masks).cuda().to(dt)
+        for bx in (boxes, None, torch.from_numpy(boxes).cuda()):
+            got = PSG.masks2segments(dm, boxes=bx)
+            assert len(got) == n
+            for g, r in zip(got, ref):
+                assert np.array_equal(g, r)
+    assert sum(len(r) for r in ref) > 50
