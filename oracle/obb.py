@@ -74,9 +74,9 @@ def batch_probiou(obb1: np.ndarray, obb2: np.ndarray) -> np.ndarray:
     return (F32(1) - hd).astype(F32)
 
 
-def nms_rotated(boxes: np.ndarray, scores: np.ndarray, threshold: float):
-    """-> (kept indices in score order, margin = min_j |max_i<j iou(i,j) - threshold|: how far the closest decision
-    is from flipping)."""
+def nms_rotated(boxes: np.ndarray, scores: np.ndarray, threshold: float, max_det=None):
+    """-> (kept indices in score order, cut to max_det; margin = min_j |max_i<j iou(i,j) - threshold| over the
+    candidates up to the last kept one: how far the closest decision that matters is from flipping)."""
     n = boxes.shape[0]
     if n == 0:
         return np.zeros((0,), np.int64), np.inf
@@ -86,7 +86,12 @@ def nms_rotated(boxes: np.ndarray, scores: np.ndarray, threshold: float):
     worst = ious.max(axis=0)
     thr = F32(threshold)
     pick = np.nonzero(worst < thr)[0]
-    margin = float(np.abs(worst[1:].astype(np.float64) - float(thr)).min()) if n > 1 else np.inf
+    if max_det is not None:
+        pick = pick[:max_det]
+    last = int(pick[-1]) if len(pick) else 0
+    if max_det is None or len(pick) < max_det:
+        last = n - 1          # every candidate was decided
+    margin = float(np.abs(worst[1:last + 1].astype(np.float64) - float(thr)).min()) if last >= 1 else np.inf
     return order[pick], margin
 
 
@@ -118,8 +123,7 @@ def non_max_suppression_rotated(prediction, conf_thres=0.25, iou_thres=0.45, agn
             rows, anchors = rows[top], anchors[top]
         c = rows[:, 5:6] * F32(0 if agnostic else max_wh)
         boxes = np.concatenate([rows[:, :2] + c, rows[:, 2:4], rows[:, -1:]], axis=1).astype(F32)
-        keep, margin = nms_rotated(boxes, rows[:, 4], iou_thres)
-        keep = keep[:max_det]
+        keep, margin = nms_rotated(boxes, rows[:, 4], iou_thres, max_det)
         out.append((rows[keep], anchors[keep], margin))
     return out
 

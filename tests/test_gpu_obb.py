@@ -115,3 +115,22 @@ def test_obb_predict_against_oracle(obb):
         assert np.array_equal(out['scores'].cpu().numpy() if as_tensor else out['scores'], rows[:, 4])
     none, _ = obb.predict(frame, 0.9999999, operators=operators)
     assert len(none['boxes']) == 0
+
+
+def test_rotated_nms_more_candidates_than_the_lds_sort_buffer():
+    """4116 anchors, every one a candidate (> 4096): the sort and the covariance arrays fall back to global memory;
+    max_det cuts the kept list at 300."""
+    from object_detectors_amd import hip_ops as ops
+    rng = np.random.default_rng(11)
+    nc = 5
+    p = synth.head(rng, 2, nc, 1, 448, objects=30)
+    p[:, -1] = (np.tanh(p[:, -1]) * 0.5 + 0.25) * math.pi
+    assert p.shape[2] == 4116
+    det, count, anchor = ops.nms_v8(torch.from_numpy(p).cuda(), 0.0005, 0.3, nc=nc, max_det=300, rotated=True)
+    torch.cuda.synchronize()
+    ref = OO.non_max_suppression_rotated(p, 0.0005, 0.3, nc=nc, max_det=300)
+    for b in range(2):
+        rows, ra, margin = ref[b]
+        assert margin > 2e-5 and len(ra) == 300
+        assert int(count[b]) == 300 and anchor[b].cpu().numpy().tolist() == ra.tolist()
+        assert np.array_equal(det[b].cpu().numpy(), rows)
