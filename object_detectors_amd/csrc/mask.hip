@@ -301,7 +301,11 @@ struct MaskOut<float> {
   static __device__ __forceinline__ void store_vec(float *p, const uint32_t bits) {
     *reinterpret_cast<float4 *>(p) = make_float4((bits & 1u) ? 1.f : 0.f, (bits & 2u) ? 1.f : 0.f, (bits & 4u) ? 1.f : 0.f, (bits & 8u) ? 1.f : 0.f);
   }
-  static __device__ __forceinline__ void store_vec_nt(float *p, const uint32_t bits) { store_vec(p, bits); }
+  static __device__ __forceinline__ void store_vec_nt(float *p, const uint32_t bits) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 v = {(bits & 1u) ? 1.f : 0.f, (bits & 2u) ? 1.f : 0.f, (bits & 4u) ? 1.f : 0.f, (bits & 8u) ? 1.f : 0.f};
+    __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+  }
   static __device__ __forceinline__ void store1(float *p, bool on) { *p = on ? 1.0f : 0.0f; }
 };
 
