@@ -102,3 +102,89 @@ def test_boxes_on_the_frame_border_and_outside(ops):
     for g, rr in zip(got, ref):
         assert (g != rr).sum() <= max(2, 0.001 * rr.sum())
     assert got[3].sum() == 0            # zero-width box
+
+
+def test_letterbox_random_geometries_one_ragged_batch(ops):
+    """Differential sweep: 48 random frame sizes (tiny to wide, up- and down-scales, odd strides of the scale factor) in
+    ragged batches against the oracle, bit for bit, over the option combinations."""
+    rng = np.random.default_rng(2024)
+    sizes = [(int(rng.integers(1, 300)), int(rng.integers(1, 400))) for _ in range(40)]
+    sizes += [(719, 1279), (1081, 1921), (97, 1003), (1003, 97), (640, 640), (641, 639), (320, 320), (159, 161)]
+    frames = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    dframes = [dev(f) for f in frames]
+    for (dh, dw), fp16, stretch, swap, pad in [((160, 160), False, False, True, 114), ((96, 224), True, False, False, 0),
+                                               ((224, 96), False, True, True, 255), ((320, 320), False, False, False, 114)]:
+        got, gops = ops.letterbox(dframes, (dh, dw), pad_value=pad, swap_rb=swap, fp16=fp16, stretch=stretch)
+        got = got.cpu().numpy()
+        view = np.uint16 if fp16 else np.uint32
+        for b, f in enumerate(frames):
+            ref, rops = OC.letterbox_u8(f, dh, dw, pad_value=pad, swap_rb=swap, fp16=fp16, stretch=stretch)
+            assert gops[b] == rops, (sizes[b], dh, dw)
+            bad = np.argwhere(got[b].view(view) != ref.view(view))
+            assert bad.shape[0] == 0, f"frame {sizes[b]} -> {(dh, dw)} stretch={stretch}: {bad.shape[0]} mismatches, first {bad[:4].tolist()}"
+
+
+def test_nms_random_configurations_with_score_ties(ops):
+    """Differential sweep over head shapes and NMS settings; scores quantised to 1/128 so that many candidates tie
+    and the order rule (equal scores keep anchor order, torch.sort stable) decides the kept set."""
+    rng = np.random.default_rng(77)
+    for trial in range(24):
+        nc = int(rng.choice([1, 2, 7, 80]))
+        nm = int(rng.choice([0, 0, 32, 5]))
+        A = int(rng.choice([64, 333, 1000, 2100, 4116]))
+        B = int(rng.integers(1, 4))
+        p = synth.head(rng, B, nc, nm, 320, objects=int(rng.integers(0, 30)), anchors=A)
+        p[:, 4:4 + nc] = np.round(p[:, 4:4 + nc] * 128) / 128            # ties, including exact threshold hits
+        conf = float(rng.choice([0.25, 0.5, 1 / 128, 0.0]))
+        iou = float(rng.choice([0.45, 0.3, 0.7, 0.0, 1.0]))
+        agnostic = bool(rng.integers(0, 2))
+        max_det = int(rng.choice([300, 5, 1, 64]))
+        det, count, anchor = ops.nms_v8(dev(p), conf, iou, agnostic=agnostic, max_det=max_det, nc=nc)
+        torch.cuda.synchronize()
+        ref = ON.non_max_suppression(p, conf, iou, agnostic=agnostic, max_det=max_det, nc=nc)
+        for b in range(B):
+            rd, ra = ref[b]
+            n = int(count[b])
+            tag = f"trial {trial}: nc={nc} nm={nm} A={A} conf={conf} iou={iou} agnostic={agnostic} max_det={max_det} image {b}"
+            assert anchor[b, :n].cpu().numpy().tolist() == ra.tolist(), tag
+            assert n == 0 or np.abs(det[b, :n].cpu().numpy() - rd).max() <= 1e-3, tag
+
+
+def test_process_mask_random_shapes(ops):
+    """Differential sweep over prototype sizes (odd widths and non-square included), frame sizes and box layouts."""
+    rng = np.random.default_rng(303)
+    nm = 32
+    for trial in range(14):
+        mh, mw = int(rng.choice([20, 25, 40, 41, 80])), int(rng.choice([20, 25, 40, 52, 80]))
+        h0, w0 = int(rng.integers(17, 400)), int(rng.integers(17, 500))
+        B, max_det = int(rng.integers(1, 4)), 16
+        proto = synth.proto(rng, B, nm, mh, mw)
+        det = np.zeros((B, max_det, 6 + nm), F32)
+        n = rng.integers(0, max_det + 1, B)
+        slot_map, slot_base = [], [0]
+        for b in range(B):
+            x1, y1 = rng.random(n[b]) * w0 * 0.8, rng.random(n[b]) * h0 * 0.8
+            det[b, :n[b], 0], det[b, :n[b], 1] = x1, y1
+            det[b, :n[b], 2] = np.minimum(x1 + rng.uniform(0.5, 0.6 * w0, n[b]), w0)
+            det[b, :n[b], 3] = np.minimum(y1 + rng.uniform(0.5, 0.6 * h0, n[b]), h0)
+            det[b, :n[b], 6:] = rng.normal(0, 0.5, (n[b], nm))
+            slot_map += [b * max_det + i for i in range(n[b])]
+            slot_base.append(len(slot_map))
+        total = slot_base[-1]
+        if total == 0:
+            continue
+        sm = np.full(B * max_det, -1, np.int32)
+        sm[:total] = slot_map
+        dtype = torch.uint8 if trial % 2 else torch.float32
+        masks, ov = ops.process_mask(dev(proto), dev(det), dev(sm), dev(np.array(slot_base, np.int32)), (h0, w0), total, dtype)
+        torch.cuda.synchronize()
+        got = masks.cpu().numpy()
+        k = 0
+        for b in range(B):
+            ref = OM.process_mask_native(proto[b], det[b, :n[b], 6:], det[b, :n[b], :4], (h0, w0))
+            g = got[k:k + n[b]]
+            k += n[b]
+            tag = f"trial {trial}: proto {mh}x{mw} frame {h0}x{w0} image {b}"
+            assert g.shape == ref.shape, tag
+            diff = (g != ref).sum()
+            assert diff <= max(3, 0.001 * ref.sum()), f"{tag}: {diff} pixels differ of {int(ref.sum())} set"
