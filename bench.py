@@ -219,7 +219,12 @@ def main():
     H0, W0, S, B = cfg["h"], cfg["w"], cfg["size"], cfg["batch"]
     if proto is not None:
         from object_detectors_amd.roofline import mask_upsample_bytes
-        kernel = "mask_upsample_kernel<uint8>"
+        # lmi_mask_upsample is two passes since r01: zeros for every live slot at the memset rate, then the chunks
+        # that meet a box.  The stage is rated as ONE unit: its algorithmic bytes (every output byte once + the
+        # logits read once) over the HIP-event time around both launches; in the rocprof summary the averages of
+        # the listed kernels add up to avg_launch_ms (less the launch gaps).
+        single = os.environ.get("LMI_MASK_UPSAMPLE") == "single"
+        kernel = "mask_upsample_kernel<uint8>" if single else "mask_zero_fill_kernel+mask_box_kernel<uint8>"
         ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
         alg = mask_upsample_bytes(n_surv, H0, W0, S // 4, S // 4)
     else:
@@ -235,7 +240,8 @@ def main():
     if os.path.isfile(tpath):
         with open(tpath) as f:
             tk = json.load(f).get("kernels", {})
-        traffic = tk.get(kernel.split("<")[0], {}).get("traffic")
+        parts = [tk.get(k.split("<")[0], {}).get("traffic") for k in kernel.split("+")]
+        traffic = sum(parts) if all(p is not None for p in parts) else None
     # measured device-to-device copy bandwidth on this box (read + write bytes), quoted beside the spec peak
     src = torch.empty(1 << 30, dtype=torch.uint8, device=device)
     dst = torch.empty_like(src)

@@ -225,7 +225,7 @@ int lmi_mask_logits(const float *proto, int batch, int nm, int mh, int mw, const
                     int max_det, int det_stride, const int32_t *slot_map, const int32_t *slot_base,
                     int h0, int w0, int64_t capacity_masks, void *workspace,
                     int64_t workspace_bytes, void *stream);
-int lmi_mask_upsample(const void *workspace, int batch, int nm, int mh, int mw, const float *det,
+int lmi_mask_upsample(void *workspace, int batch, int nm, int mh, int mw, const float *det,
                       int max_det, int det_stride, const int32_t *slot_map,
                       const int32_t *slot_base, int h0, int w0, void *out_masks, int out_dtype,
                       int64_t capacity_masks, int32_t *overflow, void *stream);

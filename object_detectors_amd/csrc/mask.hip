@@ -10,10 +10,16 @@
 //                        fmaf chain on the vector ALU (v_pk_fma_f32); proto is read once.
 //  mask_gemm_kernel      the same product as dense 32-survivor tiles on the exact-fp32 MFMA
 //                        (v_mfma_f32_32x32x2_f32); kept for odd prototype widths.
-//  mask_upsample_kernel  per survivor, per strip of output rows: stages the few logits rows the
-//                        strip needs in LDS, then bilinear (align_corners=False) -> box crop ->
-//                        `> 0`, 16 bytes per lane per store.  HBM-write-bound: m*H0*W0 bytes of
-//                        uint8 per image are written exactly once (zeros outside the box included).
+//  The upsample is HBM-write-bound (m*H0*W0 bytes of uint8 per image, ~97 % of them zeros outside the boxes) and
+//  runs as two passes when output rows are whole 16-byte chunks:
+//  mask_slot_table_kernel  per slot, the integer pixel ranges of its box.
+//  mask_zero_fill_kernel   zeros for all live slots from ONE workgroup per CU: the write pattern that reaches the
+//                        memset rate (6.4 TB/s; profiles/r01/write_ceiling.md).
+//  mask_box_kernel       the chunks that meet a box: bilinear (align_corners=False) -> box crop -> `> 0`
+//                        from logits rows staged in LDS, 16 bytes per lane per store.
+//  mask_upsample_kernel  the same result in one pass (per survivor, per strip of output rows, zeros included),
+//                        for row lengths that are not whole chunks; `LMI_MASK_UPSAMPLE=single` selects it for
+//                        every shape (measurement).
 #include <cstdlib>
 #include <cstring>
 
@@ -262,6 +268,7 @@ struct UpParams {
   MaskGeom g;
   int rows_per_block;
   int lds_rows;  // logits rows the LDS buffer can hold
+  const int4 *table;  // split path: per-slot pixel ranges of the box {xa, xb, ya, yb}
   int *overflow;
 };
 
@@ -309,6 +316,154 @@ struct MaskOut<float> {
   static __device__ __forceinline__ void store1(float *p, bool on) { *p = on ? 1.0f : 0.0f; }
 };
 
+// Integer pixel ranges of a box: x >= x1 && x < x2  <=>  ceil(x1) <= x < ceil(x2) for integer x (same for y),
+// clamped to the frame; all zero when the box holds no pixel (NaN included).
+__device__ __forceinline__ int4 box_ranges(float bx1, float by1, float bx2, float by2, int H0, int W0) {
+  if (!(bx1 < bx2 && by1 < by2)) return make_int4(0, 0, 0, 0);
+  const int xa = (int)ceilf(fminf(fmaxf(bx1, 0.0f), (float)W0)), xb = (int)ceilf(fminf(fmaxf(bx2, 0.0f), (float)W0));
+  const int ya = (int)ceilf(fminf(fmaxf(by1, 0.0f), (float)H0)), yb = (int)ceilf(fminf(fmaxf(by2, 0.0f), (float)H0));
+  if (xa >= xb || ya >= yb) return make_int4(0, 0, 0, 0);
+  return make_int4(xa, xb, ya, yb);
+}
+
+// one record per slot {xa, xb, ya, yb}: lets the box-only strip kernel decide with ONE load whether it has work
+__global__ __launch_bounds__(256) void mask_slot_table_kernel(UpParams U, int4 *table) {
+  const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (s >= U.capacity) return;
+  const long long total = min((long long)U.slot_base[U.batch], U.capacity);
+  if (s >= total) { table[s] = make_int4(0, 0, 0, 0); return; }   // dead slot: no rows, the strip kernel leaves at once
+  const float *d = U.det + (size_t)U.slot_map[s] * U.det_stride;
+  table[s] = box_ranges(d[0], d[1], d[2], d[3], U.g.h0, U.g.w0);
+}
+
+// Zeros for every live slot, written the way that reaches the memset rate on MI355X (profiles/r01/write_ceiling.md):
+// ONE workgroup per CU at most, grid-stride over 16-byte chunks, so that at any moment the chip writes one compact
+// ~1 MiB window that sweeps the buffer in address order (6.36 TB/s; thousands of workgroups each streaming its own
+// strip stay at 5.5-5.7 TB/s).  With a single wave per SIMD nothing hides latency, so the loop is kept to a handful
+// of instructions: no box test here -- mask_upsample_kernel (box_only) overwrites the few per cent of chunks that
+// meet a box afterwards.
+__global__ __launch_bounds__(256) void mask_zero_fill_kernel(const int *__restrict__ slot_base, int batch, long long capacity,
+                                                            long long chunks_per_slot, uint4 *__restrict__ out, int *__restrict__ overflow) {
+  const long long total_all = slot_base[batch];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && overflow) *overflow = total_all > capacity ? (int)(total_all - capacity) : 0;
+  const long long total = total_all < capacity ? total_all : capacity;
+  const long long n = total * chunks_per_slot;
+  const long long stride = (long long)gridDim.x * 256;
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  const u4 zero = {0u, 0u, 0u, 0u};
+  u4 *o = reinterpret_cast<u4 *>(out);
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n; g += stride) {
+    __builtin_nontemporal_store(zero, o + g);   // plain stores run as fast here but leave write-backs that slow the next kernels
+  }
+}
+
+// Second pass of the split path: the chunks that meet a slot's box, and nothing else.  grid: x = row strips, y = slot.
+// Every lane owns one 16-byte chunk column of the box and walks down the strip's box rows, so the horizontal taps and
+// weights of its pixels are computed once and all lanes of a wave have work (a lane-per-chunk sweep over whole rows
+// leaves ~3/4 of the lanes idle on boxes ~1/7 of the frame wide).  Same arithmetic as mask_upsample_kernel.
+template <typename OutT>
+__global__ __launch_bounds__(256) void mask_box_kernel(UpParams U) {
+  using MO = MaskOut<OutT>;
+  constexpr int PX = MO::PX;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *L = reinterpret_cast<float *>(smem);
+
+  const long long slot = blockIdx.y;
+  const int4 t = U.table[slot];   // zeros beyond the live slots and for boxes that hold no pixel
+  const int ra = max((int)blockIdx.x * U.rows_per_block, t.z), rb = min(((int)blockIdx.x + 1) * U.rows_per_block, t.w);
+  if (ra >= rb) return;           // most workgroups: no row of the box in this strip
+  const int H0 = U.g.h0, W0 = U.g.w0;
+  const int wh = U.g.bottom - U.g.top, ww = U.g.right - U.g.left, mw = U.g.mw;
+  const float scale_h = (float)wh / (float)H0, scale_w = (float)ww / (float)W0;
+  OutT *out = reinterpret_cast<OutT *>(U.out) + (size_t)slot * H0 * W0;
+
+  const int ca = t.x / PX, cb = (t.y + PX - 1) / PX;   // chunk columns that meet the box (rows are whole chunks)
+  // Staged: the logits rows this strip's box rows read, and of those only the columns its chunk columns read, plus
+  // one more column (the last logits column repeated past the right border): the right-hand tap of a pixel is then
+  // always the next float -- ix1 == ix0 only at the right border, where both taps read the last column -- and one
+  // 8-byte LDS read fetches both.
+  int c_lo, ls, ly_first;
+  {
+    int i0, i1, j0, j1; float l0, l1;
+    bilinear_src(scale_w, ca * PX, ww, c_lo, i1, l0, l1);
+    bilinear_src(scale_w, cb * PX - 1, ww, j0, j1, l0, l1);
+    ls = j0 + 2 - c_lo;                   // columns c_lo .. j0 + 1
+    bilinear_src(scale_h, ra, wh, i0, i1, l0, l1);
+    ly_first = i0;
+    bilinear_src(scale_h, rb - 1, wh, j0, j1, l0, l1);
+    const int nrows = j1 - ly_first + 1;  // <= U.lds_rows by construction on the host
+    const float *src = U.logits + (size_t)slot * wh * mw + (size_t)ly_first * mw + U.g.left;
+    for (int idx = threadIdx.x; idx < nrows * ls; idx += 256) {
+      const int r = idx / ls, c = idx - r * ls;
+      L[idx] = src[(size_t)r * mw + min(c_lo + c, ww - 1)];
+    }
+    __syncthreads();
+  }
+
+  const int lpr = min(cb - ca, 256);                   // lanes per row
+  const int groups = 256 / lpr;                        // row groups: each takes consecutive rows of the strip
+  const int lr = threadIdx.x / lpr, lc = threadIdx.x - lr * lpr;
+  if (lr >= groups) return;
+  const int rows_per_group = (rb - ra + groups - 1) / groups;
+  const int y_first = ra + lr * rows_per_group, y_last = min(y_first + rows_per_group, rb);
+  for (int chunk = ca + lc; chunk < cb; chunk += lpr) {
+    const int x0 = chunk * PX;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    int oa[PX];   // byte offset of the left tap within a staged row
+    f2 wx[PX];    // its weights {left, right}
+    uint32_t xmask = 0;
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+      int ia, ib;
+      float la, lb;
+      bilinear_src(scale_w, x0 + k, ww, ia, ib, la, lb);
+      oa[k] = (ia - c_lo) * 4;
+      wx[k] = f2{la, lb};
+      if (x0 + k >= t.x && x0 + k < t.y) xmask |= 1u << k;
+    }
+    typedef float taps __attribute__((ext_vector_type(2), aligned(4)));
+    // horizontal interpolation of one staged row at pixel k: depends on the source row only, so it is kept in
+    // registers across the consecutive output rows that share a source row pair (12 rows at 1080p from 160x160)
+    auto hrow = [&](int iy, int k) -> float {
+      const taps a = *reinterpret_cast<const taps *>(reinterpret_cast<const char *>(L + (iy - ly_first) * ls) + oa[k]);
+      const f2 p = f2{a.x, a.y} * wx[k];   // packed fp32 multiply, each half rounded as the scalar form
+      return p.x + p.y;
+    };
+    f2 tt[PX];   // {upper, lower} source row, interpolated horizontally
+    int cur0 = -1, cur1 = -1;
+    for (int y = y_first; y < y_last; ++y) {
+      int iy0, iy1; float ly0, ly1;
+      bilinear_src(scale_h, y, wh, iy0, iy1, ly0, ly1);
+      if (iy0 != cur0 || iy1 != cur1) {
+        if (iy0 == cur1) {
+#pragma unroll
+          for (int k = 0; k < PX; ++k) tt[k].x = tt[k].y;
+        } else {
+#pragma unroll
+          for (int k = 0; k < PX; ++k) tt[k].x = hrow(iy0, k);
+        }
+        if (iy1 == iy0) {
+#pragma unroll
+          for (int k = 0; k < PX; ++k) tt[k].y = tt[k].x;
+        } else {
+#pragma unroll
+          for (int k = 0; k < PX; ++k) tt[k].y = hrow(iy1, k);
+        }
+        cur0 = iy0; cur1 = iy1;
+      }
+      const f2 lyv = {ly0, ly1};
+      uint32_t bits = 0;
+#pragma unroll
+      for (int k = 0; k < PX; ++k) {
+        const f2 q = tt[k] * lyv;
+        if (q.x + q.y > 0.0f) bits |= 1u << k;
+      }
+      OutT *p = out + (size_t)y * W0 + x0;
+      MO::store_vec_nt(p, bits & xmask);
+    }
+  }
+}
+
 // grid: x = row strips, y = slot
 template <typename OutT>
 __global__ __launch_bounds__(256) void mask_upsample_kernel(UpParams U) {
@@ -317,8 +472,8 @@ __global__ __launch_bounds__(256) void mask_upsample_kernel(UpParams U) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *L = reinterpret_cast<float *>(smem);
 
-  const int total = U.slot_base[U.batch];
   const long long slot = blockIdx.y;
+  const int total = U.slot_base[U.batch];
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && U.overflow)
     *U.overflow = total > U.capacity ? (int)(total - U.capacity) : 0;  // survivors that did not fit
   if (slot >= total || slot >= U.capacity) return;
@@ -410,7 +565,8 @@ extern "C" {
 
 int64_t lmi_mask_workspace_bytes(int64_t capacity_masks, int mh, int mw) {
   if (capacity_masks <= 0 || mh <= 0 || mw <= 0) return 0;
-  return (int64_t)align_up((size_t)capacity_masks * mh * mw * sizeof(float), 256);
+  // logits (capacity x mh x mw fp32) + one int4 box record per slot
+  return (int64_t)(align_up((size_t)capacity_masks * mh * mw * sizeof(float), 256) + align_up((size_t)capacity_masks * sizeof(int4), 256));
 }
 
 static int mask_check_common(const char *fn, int batch, int nm, int mh, int mw, int h0, int w0, int max_det, int det_stride,
@@ -458,7 +614,7 @@ int lmi_mask_logits(const float *proto, int batch, int nm, int mh, int mw, const
   return lmi_check_launch("mask_gemm_kernel");
 }
 
-int lmi_mask_upsample(const void *workspace, int batch, int nm, int mh, int mw, const float *det, int max_det, int det_stride,
+int lmi_mask_upsample(void *workspace, int batch, int nm, int mh, int mw, const float *det, int max_det, int det_stride,
                       const int32_t *slot_map, const int32_t *slot_base, int h0, int w0, void *out_masks, int out_dtype,
                       int64_t capacity_masks, int32_t *overflow, void *stream) {
   LMI_REQUIRE(workspace && det && slot_map && slot_base && out_masks, LMI_ERR_BAD_ARG, "lmi_mask_upsample: NULL pointer");
@@ -482,9 +638,42 @@ int lmi_mask_upsample(const void *workspace, int batch, int nm, int mh, int mw, 
   }
   LMI_REQUIRE((size_t)lds_rows * ww * sizeof(float) <= 64 * 1024, LMI_ERR_LIMIT, "lmi_mask_upsample: prototype rows too wide for LDS (%d)", ww);
   U.rows_per_block = rpb; U.lds_rows = lds_rows;
-  const size_t lds = (size_t)lds_rows * ww * sizeof(float);
-  dim3 ugrid((h0 + rpb - 1) / rpb, (unsigned)capacity_masks);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // Split path (rows are whole 16-byte chunks): zeros for every live slot at the memset rate, then mask_box_kernel
+  // overwrites only the chunks that meet a box.  LMI_MASK_UPSAMPLE=single keeps the one-kernel path (measurement).
+  const int px = out_dtype == LMI_U8 ? 16 : 4;
+  const char *single = getenv("LMI_MASK_UPSAMPLE");
+  const bool split = (w0 % px) == 0 && !(single && strcmp(single, "single") == 0);
+  U.table = nullptr;
+  if (split) {
+    int4 *table = reinterpret_cast<int4 *>(reinterpret_cast<char *>(workspace) + align_up((size_t)capacity_masks * mh * mw * sizeof(float), 256));
+    U.table = table;
+    hipLaunchKernelGGL(mask_slot_table_kernel, dim3((unsigned)((capacity_masks + 255) / 256)), dim3(256), 0, s, U, table);
+    int ncu = 256, dev = 0;   // one workgroup per CU: the compact write window (see the kernel)
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+      ncu = 256;
+    hipLaunchKernelGGL(mask_zero_fill_kernel, dim3(ncu), dim3(256), 0, s, slot_base, batch, (long long)capacity_masks,
+                       (long long)h0 * (w0 / px), reinterpret_cast<uint4 *>(out_masks), overflow);
+    int rc2 = lmi_check_launch("mask_zero_fill_kernel");
+    if (rc2) return rc2;
+    // the box pass is ALU-bound, not store-bound: tall strips, so that a lane's horizontal taps serve many rows
+    rpb = 256;
+    for (;; rpb >>= 1) {
+      lds_rows = (int)((double)rpb * (double)wh / (double)h0) + 3;
+      if (lds_rows > wh) lds_rows = wh;
+      if ((size_t)lds_rows * (ww + 1) * sizeof(float) <= 48 * 1024 || rpb == 1) break;
+    }
+    U.rows_per_block = rpb; U.lds_rows = lds_rows;
+  }
+  const size_t lds = (size_t)lds_rows * (ww + (split ? 1 : 0)) * sizeof(float);
+  dim3 ugrid((h0 + rpb - 1) / rpb, (unsigned)capacity_masks);
+  if (split) {
+    if (out_dtype == LMI_U8)
+      hipLaunchKernelGGL(mask_box_kernel<uint8_t>, ugrid, dim3(256), lds, s, U);
+    else
+      hipLaunchKernelGGL(mask_box_kernel<float>, ugrid, dim3(256), lds, s, U);
+    return lmi_check_launch("mask_box_kernel");
+  }
   if (out_dtype == LMI_U8)
     hipLaunchKernelGGL(mask_upsample_kernel<uint8_t>, ugrid, dim3(256), lds, s, U);
   else

@@ -29,6 +29,9 @@ WIDE_READS = {
     "mask_gemm_kernel": True,        # float4 loads of the prototype planes
     "mask_logits_rows_kernel": False,  # 8 B per lane loads of the prototype planes (uncalibrated width)
     "mask_upsample_kernel": False,   # dword loads of logits rows (small beside the writes)
+    "mask_slot_table_kernel": False,
+    "mask_zero_fill_kernel": False,  # no reads
+    "mask_box_kernel": False,        # dword loads of logits rows
 }
 
 

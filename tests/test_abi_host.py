@@ -63,7 +63,8 @@ def test_letterbox_geometry_matches_oracle(lib):
 def test_argument_validation_needs_no_gpu(lib):
     # every check below fails before any HIP call is made
     assert lib.lmi_nms_workspace_bytes(64, 8400) > 64 * 8400 * 28
-    assert lib.lmi_mask_workspace_bytes(10, 160, 160) == 10 * 160 * 160 * 4
+    # logits (capacity x mh x mw fp32) + one 16-byte box record per slot, each rounded up to 256 bytes
+    assert lib.lmi_mask_workspace_bytes(10, 160, 160) == 10 * 160 * 160 * 4 + 256
     assert lib.lmi_preprocess_u8(None, 4, 4, 3, 12, None, 0, None) == -1
     assert lib.lmi_nms_v8(None, 1, 80, 0, 8400, 0.25, 0.45, 0, 300, 30000, 7680.0, None, None, None, None, 0, None) == -1
     assert lib.lmi_process_mask(None, 1, 32, 160, 160, None, 300, 38, None, None, 1080, 1920, None, 2, 10, None, None, 0, None) == -1
