@@ -43,7 +43,7 @@ enum lmi_status {
 enum lmi_dtype { LMI_F32 = 0, LMI_F16 = 1, LMI_U8 = 2 };
 
 /* resampler of the letterbox entry: the fixed-point cv2.INTER_LINEAR (default) */
-enum lmi_resize_mode { LMI_RESIZE_CV2_LINEAR = 0 };
+enum lmi_resize_mode { LMI_RESIZE_CV2_LINEAR = 0, LMI_RESIZE_TORCH_BILINEAR = 1 };
 
 #define LMI_MAX_DET_CAP 1024   /* largest max_det lmi_nms_v8 accepts */
 #define LMI_MAX_MASK_DIM 32    /* number of prototype channels (nm) the mask kernels are built for */
@@ -102,6 +102,15 @@ typedef struct lmi_frame {
  *   swap_rb != 0 reverses the channel order (BGR<->RGB); pad_value in 0..255.
  *   workspace   [device] >= lmi_letterbox_workspace_bytes(batch, dst_h, dst_w) bytes, 256-byte
  *               aligned: the per-frame coefficient tables, rebuilt by every call
+ * mode = LMI_RESIZE_TORCH_BILINEAR swaps the resampler for the reference's own helper flavour
+ *   `resize_image` + `fit_im_to_size`   lmi_utils/gadget_utils/pipeline_utils.py:23-142, as chained by
+ *                                        object_detectors/ultralytics_lmi/yolo/run_model.py:87-100
+ * i.e. F.interpolate(bilinear, align_corners=False) on the fp32 cast of the frame, truncating cast
+ * back to uint8, then the centred pad -- or centred CROP: in this mode pad_l / pad_t may be negative
+ * and the content may overhang the destination.  Bit-exact against aten's CPU kernels of torch 2.10
+ * on >= 2 threads (aten computes differently on exactly one thread; tests/golden/letterbox_torch.npz,
+ * oracle/geometry.py; aten switches between two kernels at new_h + new_w = 128, so does this one, per
+ * frame).  workspace is not used (may be NULL).
  */
 int64_t lmi_letterbox_workspace_bytes(int table_sets, int dst_h, int dst_w);
 int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, int batch,

@@ -369,6 +369,93 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restri
   }
 }
 
+// The LMI-flavoured caller-side resize: `resize_image` = F.interpolate(bilinear) on the
+// fp32 cast of the frame, truncating cast back to uint8, then `fit_im_to_size` = centred constant pad, or centred
+// crop where the content is larger than the destination (lmi_utils/gadget_utils/pipeline_utils.py:23-142, chained
+// by ultralytics_lmi/yolo/run_model.py:87-100), then preprocess.  The arithmetic is aten's CPU kernel as built for
+// x86 (oracle/geometry.py:resize_bilinear, pinned by tests/golden/letterbox_torch.npz): source coordinate
+// fma(scale, d + 0.5, -0.5) clamped at 0; then the per-pixel 4-weight kernel aten runs when out_h + out_w <= 128,
+// else its separable kernel (horizontal pairs, then vertical, each fma(a, wa, b*wb)).
+// One lane = 4 output pixels x 3 channels; taps are read straight from L2/HBM (12 bytes per tap pair).
+__device__ __forceinline__ void aten_linear_src(float scale, int d, int in_n, int &i0, int &i1, float &l0, float &l1) {
+  float s = fmaxf(fmaf(scale, (float)d + 0.5f, -0.5f), 0.0f);
+  i0 = min((int)s, in_n - 1);
+  i1 = i0 + ((i0 < in_n - 1) ? 1 : 0);
+  l1 = fminf(fmaxf(s - (float)i0, 0.0f), 1.0f);
+  l0 = 1.0f - l1;
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void letterbox_torch_kernel(LbParams P) {
+  using TR = OutTraits<OutT>;
+  using reg_t = typename TR::reg;
+  const int b = blockIdx.z;
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  if (y >= P.dst_h || x0 >= P.dst_w) return;
+  const uint8_t *src;
+  int h, w, new_w, new_h, pad_l, pad_t;
+  long long stride;
+  frame_of(P, b, src, h, w, stride, new_w, new_h, pad_l, pad_t);
+  const bool weights4 = new_h + new_w <= 128;   // aten's choice between its two CPU kernels (3 channels, >= 2 threads)
+  const reg_t pv = TR::make(P.pad_value);
+  reg_t out[3][4];
+  const int dy = y - pad_t;
+  const bool row_in = dy >= 0 && dy < new_h;
+  int iy0 = 0, iy1 = 0;
+  float ly0 = 0.f, ly1 = 0.f;
+  if (row_in) aten_linear_src((float)h / (float)new_h, dy, h, iy0, iy1, ly0, ly1);
+  const float scale_w = (float)w / (float)new_w;
+  const uint8_t *r0 = src + (long long)iy0 * stride, *r1 = src + (long long)iy1 * stride;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int dx = x0 + k - pad_l;
+    if (!row_in || dx < 0 || dx >= new_w) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) out[c][k] = pv;
+      continue;
+    }
+    int ix0, ix1;
+    float lx0, lx1;
+    aten_linear_src(scale_w, dx, w, ix0, ix1, lx0, lx1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float i00 = (float)r0[ix0 * 3 + c], i01 = (float)r0[ix1 * 3 + c];
+      const float i10 = (float)r1[ix0 * 3 + c], i11 = (float)r1[ix1 * 3 + c];
+      float v;
+      if (weights4) {
+        const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+        v = fmaf(w11, i11, fmaf(w10, i10, fmaf(w00, i00, w01 * i01)));
+      } else {
+        const float t0 = fmaf(i00, lx0, i01 * lx1), t1 = fmaf(i10, lx0, i11 * lx1);
+        v = fmaf(t0, ly0, t1 * ly1);
+      }
+      out[c][k] = TR::make((int)v);   // `.to(uint8)`: truncation (the value lies in [0, 255.00002])
+    }
+  }
+  const long long plane = (long long)P.dst_h * P.dst_w;
+  OutT *dst = reinterpret_cast<OutT *>(P.dst) + (long long)b * 3 * plane;
+  const bool vec = (P.dst_w & 3) == 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    OutT *p = dst + (P.swap_rb ? 2 - c : c) * plane + (long long)y * P.dst_w + x0;
+    if (x0 + 3 < P.dst_w) {
+      if (vec) TR::store4nt(p, out[c]); else TR::store4(p, out[c], false);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (x0 + k < P.dst_w) TR::store1(p + k, out[c][k]);
+    }
+  }
+}
+
+template <typename OutT>
+int launch_letterbox_torch(const LbParams &P, int batch, hipStream_t stream) {
+  dim3 grid((P.dst_w + 255) / 256, (P.dst_h + 3) / 4, batch);
+  hipLaunchKernelGGL(letterbox_torch_kernel<OutT>, grid, dim3(256), 0, stream, P);
+  return lmi_check_launch("letterbox_torch_kernel");
+}
+
 int lds_pitch_for(int w, int new_w, int tw) {
   // widest source span (pixels) a tile of `tw` output columns can touch, +1 neighbour, +alignment slack
   double scale = (double)w / (double)new_w;
@@ -437,17 +524,19 @@ int check_common(const void *dst, int dst_h, int dst_w, int dst_dtype, int pad_v
   LMI_REQUIRE(dst_h > 0 && dst_w > 0, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: bad destination size %dx%d", dst_h, dst_w);
   LMI_REQUIRE(dst_dtype == LMI_F32 || dst_dtype == LMI_F16, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: dst_dtype must be LMI_F32 or LMI_F16");
   LMI_REQUIRE(pad_value >= 0 && pad_value <= 255, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: pad_value %d not in 0..255", pad_value);
-  LMI_REQUIRE(mode == LMI_RESIZE_CV2_LINEAR, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: unknown resize mode %d", mode);
+  LMI_REQUIRE(mode == LMI_RESIZE_CV2_LINEAR || mode == LMI_RESIZE_TORCH_BILINEAR, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: unknown resize mode %d", mode);
   LMI_REQUIRE(lmi_is_aligned(dst, 16), LMI_ERR_ALIGNMENT, "lmi_letterbox_u8: dst must be 16-byte aligned");
   return LMI_OK;
 }
 
-int check_frame(const void *src, int h, int w, long long stride, int new_w, int new_h, int pad_l, int pad_t, int dst_h, int dst_w, int i) {
+int check_frame(const void *src, int h, int w, long long stride, int new_w, int new_h, int pad_l, int pad_t, int dst_h, int dst_w, int i,
+                bool may_crop = false) {
   LMI_REQUIRE(src != nullptr, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frame %d: src is NULL", i);
   LMI_REQUIRE(lmi_is_aligned(src, 16), LMI_ERR_ALIGNMENT, "lmi_letterbox_u8: frame %d: src must be 16-byte aligned", i);
   LMI_REQUIRE(h > 0 && w > 0 && stride >= 3LL * w, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frame %d: bad size/stride (%d,%d,%lld)", i, h, w, stride);
   LMI_REQUIRE((long long)(h - 1) * stride + 3LL * w < (1LL << 32) - 16, LMI_ERR_LIMIT, "lmi_letterbox_u8: frame %d larger than 4 GiB", i);
-  LMI_REQUIRE(new_w > 0 && new_h > 0 && pad_l >= 0 && pad_t >= 0 && pad_l + new_w <= dst_w && pad_t + new_h <= dst_h,
+  // the torch flavour may place the content partly outside the destination (fit_im_to_size crops, centred)
+  LMI_REQUIRE(new_w > 0 && new_h > 0 && (may_crop || (pad_l >= 0 && pad_t >= 0 && pad_l + new_w <= dst_w && pad_t + new_h <= dst_h)),
               LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frame %d: content %dx%d at (%d,%d) does not fit %dx%d", i, new_w, new_h, pad_l, pad_t, dst_w, dst_h);
   return LMI_OK;
 }
@@ -470,7 +559,8 @@ int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, 
   int p128 = 0, p32 = 0;
   for (int i = 0; i < batch; ++i) {
     const lmi_frame &f = frames_host[i];
-    rc = check_frame(reinterpret_cast<const void *>(f.src), f.h, f.w, f.row_stride, f.new_w, f.new_h, f.pad_l, f.pad_t, dst_h, dst_w, i);
+    rc = check_frame(reinterpret_cast<const void *>(f.src), f.h, f.w, f.row_stride, f.new_w, f.new_h, f.pad_l, f.pad_t, dst_h, dst_w, i,
+                     mode == LMI_RESIZE_TORCH_BILINEAR);
     if (rc) return rc;
     int a = lds_pitch_for(f.w, f.new_w, 128), b = lds_pitch_for(f.w, f.new_w, 32);
     if (a > p128) p128 = a;
@@ -480,6 +570,8 @@ int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, 
   P.frames = frames_dev;
   P.dst = dst; P.dst_h = dst_h; P.dst_w = dst_w; P.pad_value = pad_value; P.swap_rb = swap_rb ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (mode == LMI_RESIZE_TORCH_BILINEAR)   // no tables: workspace is not used
+    return dst_dtype == LMI_F32 ? launch_letterbox_torch<float>(P, batch, s) : launch_letterbox_torch<__half>(P, batch, s);
   return dst_dtype == LMI_F32 ? launch_letterbox<float>(P, batch, batch, p128, p32, workspace, workspace_bytes, s)
                               : launch_letterbox<__half>(P, batch, batch, p128, p32, workspace, workspace_bytes, s);
 }
@@ -504,6 +596,8 @@ int lmi_letterbox_u8_uniform(const void *src, int batch, int h, int w, int64_t r
   P.new_w = g[0]; P.new_h = g[1]; P.pad_l = g[2]; P.pad_t = g[4];
   P.dst = dst; P.dst_h = dst_h; P.dst_w = dst_w; P.pad_value = pad_value; P.swap_rb = swap_rb ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (mode == LMI_RESIZE_TORCH_BILINEAR)
+    return dst_dtype == LMI_F32 ? launch_letterbox_torch<float>(P, batch, s) : launch_letterbox_torch<__half>(P, batch, s);
   const int p128 = lds_pitch_for(w, g[0], 128), p32 = lds_pitch_for(w, g[0], 32);
   return dst_dtype == LMI_F32 ? launch_letterbox<float>(P, batch, 1, p128, p32, workspace, workspace_bytes, s)
                               : launch_letterbox<__half>(P, batch, 1, p128, p32, workspace, workspace_bytes, s);

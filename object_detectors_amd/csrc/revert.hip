@@ -55,8 +55,9 @@ struct MaskStage {
 };
 
 // aten upsample_bilinear2d, align_corners=False, with the contractions of torch's x86 build (oracle/geometry.py:
-// only the fused forms reproduce F.interpolate bit for bit): the source coordinate is ONE fused multiply-add and
-// each pair of taps is combined as fma(a, wa, b*wb).
+// only the fused forms reproduce F.interpolate bit for bit): the source coordinate is ONE fused multiply-add; then
+// either aten's separable kernel -- each pair of taps combined as fma(a, wa, b*wb), horizontal first -- or, for
+// outputs with dh + dw <= 128, its per-pixel kernel with four weight products (aten_linear_variant in the oracle).
 __device__ __forceinline__ void bilinear_src(float scale, int d, int in_n, int &i0, int &i1, float &l0, float &l1) {
   float s = fmaf(scale, (float)d + 0.5f, -0.5f);
   s = fmaxf(s, 0.0f);
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(256) void revert_masks_kernel(MaskStage S) {
   T v[N];
   if (S.resize) {
     const float scale_h = (float)S.vh / (float)S.dh, scale_w = (float)S.vw / (float)S.dw;
+    const bool weights4 = S.dh + S.dw <= 128;
     int iy0, iy1; float ly0, ly1;
     bilinear_src(scale_h, y, S.vh, iy0, iy1, ly0, ly1);
 #pragma unroll
@@ -123,9 +125,16 @@ __global__ __launch_bounds__(256) void revert_masks_kernel(MaskStage S) {
       const int x = x0 + k;
       int ix0, ix1; float lx0, lx1;
       bilinear_src(scale_w, min(x, S.dw - 1), S.vw, ix0, ix1, lx0, lx1);
-      const float t0 = fmaf(tap(iy0, ix0), lx0, tap(iy0, ix1) * lx1);
-      const float t1 = fmaf(tap(iy1, ix0), lx0, tap(iy1, ix1) * lx1);
-      v[k] = Px<T>::from_interp(fmaf(t0, ly0, t1 * ly1));
+      float r;
+      if (weights4) {
+        const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+        r = fmaf(w11, tap(iy1, ix1), fmaf(w10, tap(iy1, ix0), fmaf(w00, tap(iy0, ix0), w01 * tap(iy0, ix1))));
+      } else {
+        const float t0 = fmaf(tap(iy0, ix0), lx0, tap(iy0, ix1) * lx1);
+        const float t1 = fmaf(tap(iy1, ix0), lx0, tap(iy1, ix1) * lx1);
+        r = fmaf(t0, ly0, t1 * ly1);
+      }
+      v[k] = Px<T>::from_interp(r);
     }
   } else {
 #pragma unroll

@@ -83,12 +83,12 @@ def fit_im_to_size(im, W=None, H=None, value=0):
         t = t[..., None]
     t = t.permute(2, 0, 1)
     pl, pr = _axis_pads(w, W)
-    if pl >= 0:
+    if pr >= 0:   # a crop by one pixel is (0, -1): the sign of the second pad tells pad from crop
         t = F.pad(t, (pl, pr, 0, 0), value=value)
     else:
         t = t[:, :, -pl:w + pr]
     pt, pb = _axis_pads(h, H)
-    if pt >= 0:
+    if pb >= 0:
         t = F.pad(t, (0, 0, pt, pb), value=value)
     else:
         t = t[:, -pt:h + pb, :]
@@ -106,11 +106,11 @@ def fit_array_to_size(im, W=None, H=None, value=0):
     pl, pr = _axis_pads(w, W)
     pt, pb = _axis_pads(h, H)
     extra = [(0, 0)] * (im.ndim - 2)
-    if pl >= 0:
+    if pr >= 0:
         im = np.pad(im, [(0, 0), (pl, pr)] + extra, constant_values=value) if (pl or pr) else im
     else:
         im = im[:, -pl:w + pr]
-    if pt >= 0:
+    if pb >= 0:
         im = np.pad(im, [(pt, pb), (0, 0)] + extra, constant_values=value) if (pt or pb) else im
     else:
         im = im[-pt:h + pb, :]

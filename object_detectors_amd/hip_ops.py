@@ -72,17 +72,54 @@ def preprocess_u8(im: torch.Tensor, fp16: bool = False) -> torch.Tensor:
     return out
 
 
+def torch_letterbox_geometry(h: int, w: int, dst_h: int, dst_w: int, resize=None):
+    """(new_w, new_h, pad_l, pad_r, pad_t, pad_b) of the reference helpers' chain `resize_image(im, H=, W=)` then
+    `fit_im_to_size(im, H=dst_h, W=dst_w)` (lmi_utils/gadget_utils/pipeline_utils.py:36-39, :110-131): a missing
+    side keeps the aspect ratio with `int()`; pads are centred with the smaller half first, negative = centred crop.
+    resize = (H, W) as the v1 runner's `--resize h w`; None = the aspect-preserving fit into (dst_h, dst_w)."""
+    rh, rw = (None, None) if resize is None else resize
+    if rh is None and rw is None:
+        if dst_h * w <= dst_w * h:
+            rh = dst_h
+        else:
+            rw = dst_w
+    new_w = int(rw) if rw is not None else int(w * rh / h)
+    new_h = int(rh) if rh is not None else int(h * rw / w)
+
+    def split(have, want):
+        if want >= have:
+            before = (want - have) // 2
+            return before, want - have - before
+        before = (have - want) // 2
+        return -before, -(have - want - before)
+
+    pl, pr = split(new_w, dst_w)
+    pt, pb = split(new_h, dst_h)
+    return new_w, new_h, pl, pr, pt, pb
+
+
 def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple[int, int], pad_value: int = 114,
               swap_rb: bool = False, fp16: bool = False, stretch: bool = False,
-              out: Optional[torch.Tensor] = None):
-    """Fused cv2-INTER_LINEAR resize + centred pad + channel swap + /255 + NCHW.
+              out: Optional[torch.Tensor] = None, mode: str = "cv2", resize=None):
+    """Fused resize + centred pad + channel swap + /255 + NCHW.
 
     frames: a (B,H,W,3) uint8 tensor (uniform batch) or a sequence of (H,W,3) uint8 tensors of any
     sizes.  Returns (tensor (B,3,dst_h,dst_w), operators) where operators[b] is the list
     `[{'resize': [new_w,new_h,w,h]}, {'pad': [L,R,T,B]}]` that `revert_to_origin` consumes.
+    mode 'cv2': cv2.resize INTER_LINEAR (the callers' default chain); mode 'torch': the reference helpers
+    `resize_image` + `fit_im_to_size` (fp32 bilinear, truncating cast; `resize=(H, W)` as the v1 runner's
+    `--resize`, either side None; pads may be negative = centred crop; pad value 0 is the helpers' default).
     """
     dst_h, dst_w = int(dst_hw[0]), int(dst_hw[1])
     tdt, ldt = _dt(fp16)
+    if mode not in ("cv2", "torch"):
+        raise ValueError(f"letterbox: unknown mode {mode!r}")
+    if resize is not None and mode != "torch":
+        raise ValueError("letterbox: resize= belongs to mode='torch' (the cv2 flavour derives its geometry from dst_hw)")
+    if mode == "torch" and isinstance(frames, torch.Tensor):
+        if frames.ndim == 3:
+            frames = frames.unsqueeze(0)
+        frames = list(frames.unbind(0))   # geometry by the helpers' rules: the descriptor form carries it
     if isinstance(frames, torch.Tensor):
         _need_cuda(frames, "frames")
         if frames.ndim == 3:
@@ -119,7 +156,10 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
                 f = f.clone()
         keep.append(f)
         h, w, _ = f.shape
-        g = letterbox_geometry(h, w, dst_h, dst_w, stretch)
+        if mode == "torch":
+            g = torch_letterbox_geometry(h, w, dst_h, dst_w, (dst_h, dst_w) if stretch else resize)
+        else:
+            g = letterbox_geometry(h, w, dst_h, dst_w, stretch)
         desc[i] = lmi_frame(f.data_ptr(), h, w, f.stride(0), g[0], g[1], g[2], g[4], 0)
         ops.append([{"resize": [g[0], g[1], w, h]}, {"pad": [g[2], g[3], g[4], g[5]]}])
     dev = keep[0].device
@@ -129,7 +169,7 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
         out = torch.empty((len(keep), 3, dst_h, dst_w), dtype=tdt, device=dev)
     ws = _ws.get(dev, "letterbox", int(_L.lmi_letterbox_workspace_bytes(len(keep), dst_h, dst_w)))
     check(_L.lmi_letterbox_u8(C.addressof(desc), ddev.data_ptr(), len(keep), out.data_ptr(), dst_h, dst_w, ldt,
-                              pad_value, int(swap_rb), 0, ws.data_ptr(), ws.numel(), _stream()))
+                              pad_value, int(swap_rb), 1 if mode == "torch" else 0, ws.data_ptr(), ws.numel(), _stream()))
     ddev.record_stream(torch.cuda.current_stream())
     return out, ops
 

@@ -113,16 +113,16 @@ def fit_im_to_size(im: np.ndarray, W=None, H=None, value=0):
     h, w = im.shape[:2]
     pl, pr, pt, pb = fit_pads(h, w, W, H)
     out = im
-    if pl >= 0 and (pl or pr):
+    if pl < 0 or pr < 0:   # crop (a crop by one pixel is pads (0, -1))
+        out = out[:, -pl : out.shape[1] + pr]
+    elif pl or pr:
         widths = [(0, 0), (pl, pr)] + [(0, 0)] * (im.ndim - 2)
         out = np.pad(out, widths, constant_values=value)
-    elif pl < 0 or pr < 0:
-        out = out[:, -pl : out.shape[1] + pr]
-    if pt >= 0 and (pt or pb):
+    if pt < 0 or pb < 0:
+        out = out[-pt : out.shape[0] + pb]
+    elif pt or pb:
         widths = [(pt, pb), (0, 0)] + [(0, 0)] * (im.ndim - 2)
         out = np.pad(out, widths, constant_values=value)
-    elif pt < 0 or pb < 0:
-        out = out[-pt : out.shape[0] + pb]
     return out, pl, pr, pt, pb
 
 
@@ -159,20 +159,37 @@ def _bilinear_axis(in_n: int, out_n: int):
     return i0, i1, (F32(1) - l1).astype(F32), l1
 
 
-def resize_bilinear(im: np.ndarray, W: int, H: int) -> np.ndarray:
-    """resize_image(im, W, H) for an (H,W) plane: fp32 bilinear, horizontal taps first then vertical, each pair
-    combined as fma(a, wa, b*wb) -- the operation order of aten's CPU kernel as built for x86 (bit-exact against
-    F.interpolate for enlargements, see tests/test_oracle_geometry.py; aten's own result for reductions depends
-    on its vectorisation path, so those are compared with a tolerance).  Integer planes are interpolated in fp32
-    and truncated on the cast back."""
+def aten_linear_variant(channels: int, H: int, W: int, one_thread: bool = False) -> str:
+    """Which of aten's two CPU bilinear kernels F.interpolate runs for a channels-last fp32 input (what
+    `im.permute(2,0,1).unsqueeze(0)` of an HWC image is), torch 2.10 x86: the per-pixel 4-weight kernel when
+    `out_H + out_W <= 128` (or C > 3, or C == 3 on exactly one thread), else the separable generic kernel.
+    Probed in the build container: the switch sits at out_H + out_W == 129 for every width tried, 1 thread
+    differs from 2/3/8 threads only for C == 3 outputs above that size.  The two round differently."""
+    if channels > 3 or H + W <= 128 or (one_thread and channels == 3):
+        return "weights4"
+    return "separable"
+
+
+def resize_bilinear(im: np.ndarray, W: int, H: int, one_thread: bool = False) -> np.ndarray:
+    """resize_image(im, W, H) for an (H,W) plane or (H,W,C) image: fp32 bilinear with aten's operation order as
+    built for x86 (bit-exact against F.interpolate, tests/test_oracle_geometry.py), then the truncating cast back
+    for integer images.  separable kernel: horizontal taps first, then vertical, each pair as fma(a, wa, b*wb);
+    4-weight kernel: w = wy*wx products in fp32, then fma(w11,i11, fma(w10,i10, fma(w00,i00, w01*i01)))."""
     src = im.astype(F32)
     y0, y1, wy0, wy1 = _bilinear_axis(src.shape[0], H)
     x0, x1, wx0, wx1 = _bilinear_axis(src.shape[1], W)
-    wx0, wx1 = np.broadcast_to(wx0, (H, W)), np.broadcast_to(wx1, (H, W))
-    wy0, wy1 = np.broadcast_to(wy0[:, None], (H, W)), np.broadcast_to(wy1[:, None], (H, W))
-    r0 = _fma(src[y0][:, x0], wx0, (src[y0][:, x1] * wx1).astype(F32))
-    r1 = _fma(src[y1][:, x0], wx0, (src[y1][:, x1] * wx1).astype(F32))
-    out = _fma(r0, wy0, (r1 * wy1).astype(F32))
+    tail = (1,) * (src.ndim - 2)   # (H,W,C) images: every channel gets the pixel's weights
+    wx0, wx1 = wx0.reshape((1, W) + tail), wx1.reshape((1, W) + tail)
+    wy0, wy1 = wy0.reshape((H, 1) + tail), wy1.reshape((H, 1) + tail)
+    i00, i01, i10, i11 = src[y0][:, x0], src[y0][:, x1], src[y1][:, x0], src[y1][:, x1]
+    if aten_linear_variant(src.shape[2] if src.ndim == 3 else 1, H, W, one_thread) == "weights4":
+        w00, w01 = (wy0 * wx0).astype(F32), (wy0 * wx1).astype(F32)
+        w10, w11 = (wy1 * wx0).astype(F32), (wy1 * wx1).astype(F32)
+        out = _fma(w11, i11, _fma(w10, i10, _fma(w00, i00, (w01 * i01).astype(F32))))
+    else:
+        r0 = _fma(i00, wx0, (i01 * wx1).astype(F32))
+        r1 = _fma(i10, wx0, (i11 * wx1).astype(F32))
+        out = _fma(r0, wy0, (r1 * wy1).astype(F32))
     return out if np.issubdtype(im.dtype, np.floating) else out.astype(im.dtype)
 
 
@@ -196,3 +213,33 @@ def revert_mask_to_origin(mask: np.ndarray, operations) -> np.ndarray:
 
 def revert_masks_to_origin(masks: np.ndarray, operations) -> np.ndarray:
     return np.stack([revert_mask_to_origin(m, operations) for m in masks]) if len(masks) else masks
+
+
+# ---------------------------------------------------------------------------------------------
+# LMI-flavoured caller-side resize + pad: `resize_image` then `fit_im_to_size`
+# (pipeline_utils.py:23-142) as chained by the v1 runner (ultralytics_lmi/yolo/run_model.py:87-100), followed by
+# `Yolov8.preprocess` (model.py:112-134).  PINNED: tests/golden/letterbox_torch.npz holds outputs of the
+# reference's own two helpers run in the build container (tests/golden/make_golden_letterbox_torch.py), for torch
+# on >= 2 threads (aten picks another kernel, with other rounding, on exactly one thread).
+def letterbox_torch_u8(frame: np.ndarray, dst_h: int, dst_w: int, resize_w=None, resize_h=None, pad_value: int = 0,
+                       swap_rb: bool = False, fp16: bool = False):
+    """uint8 (h,w,3) -> resize_image(W=resize_w, H=resize_h) (fp32 bilinear, truncating cast; a missing side keeps
+    the aspect ratio with `int()`; both missing: the aspect-preserving fit into (dst_h, dst_w), the side that does
+    not touch the frame truncated the same way) -> fit_im_to_size(H=dst_h, W=dst_w, value=pad_value) (centred pad,
+    or centred crop where the content is larger) -> optional channel reverse -> /255 -> CHW.
+    Returns (chw, operators) with operators = [{'resize': [new_w,new_h,w,h]}, {'pad': [L,R,T,B]}]."""
+    h, w = frame.shape[:2]
+    if resize_w is None and resize_h is None:
+        if dst_h * w <= dst_w * h:
+            resize_h = dst_h
+        else:
+            resize_w = dst_w
+    new_w, new_h = resize_target(h, w, resize_w, resize_h)
+    small = resize_bilinear(frame, new_w, new_h)
+    canvas, pl, pr, pt, pb = fit_im_to_size(small, W=dst_w, H=dst_h, value=pad_value)
+    if swap_rb:
+        canvas = canvas[:, :, ::-1]
+    chw = np.ascontiguousarray(canvas.transpose(2, 0, 1))
+    q = chw.astype(F32) / F32(255.0)
+    ops = [{"resize": [new_w, new_h, w, h]}, {"pad": [pl, pr, pt, pb]}]
+    return (q.astype(np.float16) if fp16 else q), ops
