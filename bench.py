@@ -76,22 +76,40 @@ class Pipeline:
         self.capacity = 0
         self.nms_out = None
         self.fin_out = None
+        self.side = torch.cuda.Stream(device=frames.device)
+        self.decode_done = torch.cuda.Event()
 
-    def step(self, time_upsample=None, time_letterbox=None):
-        """One pass of the hot path over the batch, all on the current stream.  (Running the letterbox on a
-        second stream beside the NMS chain was measured and bought nothing: the kernels serialise on the
-        chip -- the NMS workgroups starve behind the letterbox's -- so the simple order stays.)"""
-        ops = self.ops
+    def step(self, time_upsample=None, time_letterbox=None, fork=True):
+        """One pass of the hot path over the batch.  The letterbox and the NMS chain do not depend on each other.
+        Side by side from the start they gain nothing (both the letterbox and the NMS candidate filter are
+        HBM-bound, and the sort + suppression workgroups that follow starve behind the letterbox's), so the
+        letterbox is started on a second stream at the moment the candidate filter is done: the latency-bound
+        sort + suppression pass (one workgroup per image) then shares the chip with it (det640: 0.181 -> 0.169 ms,
+        seg640: 1.312 -> 1.284 ms per step; scratch/fork_sort.py).  fork=False: everything on one stream."""
+        ops, cfg = self.ops, self.cfg
+        main = torch.cuda.current_stream()
+        if not fork:
+            self._letterbox(time_letterbox)
+            self.nms_out = ops.nms_v8(self.head, CONF, IOU, nc=cfg["nc"], max_det=MAX_DET, out=self.nms_out)
+        else:
+            self.nms_out = ops.nms_v8(self.head, CONF, IOU, nc=cfg["nc"], max_det=MAX_DET, out=self.nms_out, decode_done=self.decode_done)
+            self.side.wait_event(self.decode_done)
+            with torch.cuda.stream(self.side):
+                self._letterbox(time_letterbox)
+        out = self._post(time_upsample)
+        if fork:
+            main.wait_stream(self.side)
+        return out
+
+    def _letterbox(self, time_letterbox):
         if time_letterbox is not None:
             time_letterbox[0].record()
-        ops.letterbox(self.frames, (self.S, self.S), pad_value=114, swap_rb=True, out=self.lb_out)
+        self.ops.letterbox(self.frames, (self.S, self.S), pad_value=114, swap_rb=True, out=self.lb_out)
         if time_letterbox is not None:
             time_letterbox[1].record()
-        return self._post(time_upsample)
 
     def _post(self, time_upsample=None):
         ops, cfg = self.ops, self.cfg
-        self.nms_out = ops.nms_v8(self.head, CONF, IOU, nc=cfg["nc"], max_det=MAX_DET, out=self.nms_out)
         det, count, anchor = self.nms_out
         self.fin_out = fin = ops.finalize_detections(det, count, cfg["nc"], (self.S, self.S), (cfg["h"], cfg["w"]), MASK_CONF, out=self.fin_out)
         masks = None
@@ -143,6 +161,7 @@ def main():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per step in the timed region "
                     "(the per-kernel roofline timing then comes from an eager, event-timed pass right after it)")
+    ap.add_argument("--no-fork", action="store_true", help="run the letterbox and the NMS chain on one stream (measurement)")
     ap.add_argument("--mask-logits", default="rows", choices=["rows", "mfma"],
                     help="coefficient x prototype product: row-sparse vector-ALU kernel (default) or dense fp32 MFMA tiles "
                          "(measurement of the MFMA variant; sets LMI_MASK_LOGITS for liblmi_hip)")
@@ -169,6 +188,7 @@ def main():
     t_gen = time.perf_counter()
     frames, head, proto = make_inputs(cfg, args.seed + 1000 * rank, device)
     pipe = Pipeline(cfg, frames, head, proto)
+    fork = not args.no_fork
     log(f"[bench r{rank}] inputs ready in {time.perf_counter() - t_gen:.1f}s: {cfg['desc']}")
 
     def barrier():
@@ -178,7 +198,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(max(args.warmup, 1)):
-        out = pipe.step()
+        out = pipe.step(fork=fork)
     barrier()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     lb_evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -186,7 +206,7 @@ def main():
     if args.graph:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            out = pipe.step()
+            out = pipe.step(fork=fork)
         graph.replay()
         barrier()
     t0 = time.perf_counter()
@@ -196,12 +216,12 @@ def main():
         else:
             # HIP events go on the stream each kernel is launched on: the upsample on the main stream, the
             # letterbox (the dominant kernel of the detect workloads) on the side stream
-            out = pipe.step(time_upsample=evs[k] if proto is not None else None, time_letterbox=lb_evs[k])
+            out = pipe.step(time_upsample=evs[k] if proto is not None else None, time_letterbox=lb_evs[k], fork=fork)
     barrier()
     elapsed = time.perf_counter() - t0
     if graph is not None:   # events cannot be recorded inside a captured graph: time the kernel in eager passes
         for k in range(args.steps):
-            pipe.step(time_upsample=evs[k] if proto is not None else None, time_letterbox=lb_evs[k])
+            pipe.step(time_upsample=evs[k] if proto is not None else None, time_letterbox=lb_evs[k], fork=fork)
         barrier()
     det, count, anchor, fin, masks = out
     n_surv = int(fin["keep_count"].sum().item())
@@ -274,7 +294,7 @@ def main():
             "config": {"workload": cfg["desc"], "name": args.workload, "per_gpu_batch": B, "conf": CONF, "iou": IOU,
                        "max_det": MAX_DET, "survivors_per_batch": n_surv, "nms_kept_per_batch": n_kept,
                        "per_rank": [{"images": int(r["images"]), "survivors": int(r["survivors"]), "kept_checksum": (int(r["chk_hi"]) << 31) | int(r["chk_lo"])} for r in reports],
-                       "mask_dtype": "uint8", "forward": "excluded", "launch": "hip graph replay" if args.graph else "eager", "mask_logits": args.mask_logits, "sharding": f"{world} x independent batches, no collective on the hot path"},
+                       "mask_dtype": "uint8", "forward": "excluded", "launch": "hip graph replay" if args.graph else "eager", "streams": "letterbox forked beside NMS sort+suppress" if fork else "one", "mask_logits": args.mask_logits, "sharding": f"{world} x independent batches, no collective on the hot path"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(res), flush=True)

@@ -146,6 +146,19 @@ int lmi_nms_v8(const float *pred, int batch, int nc, int nm, int anchors, float 
                double iou_thres, int agnostic, int max_det, int max_nms, float max_wh,
                float *out_det, int32_t *out_count, int32_t *out_anchor, void *workspace,
                int64_t workspace_bytes, void *stream);
+/* The two halves of lmi_nms_v8 / lmi_nms_v8_rotated (same reference lines), exported so that a caller can
+ * schedule between them: lmi_nms_decode is the candidate filter (HBM-bound, reads the head once into
+ * `workspace`); lmi_nms_suppress is sort + suppression from `workspace` (one workgroup per image, latency-bound,
+ * next to no HBM traffic -- it shares the chip well with an HBM-bound kernel on another stream, e.g. the next
+ * batch's letterbox started on an event recorded between the two calls; bench.py does that).  Same arguments
+ * and workspace as lmi_nms_v8; rotated != 0 selects the oriented-box suppression.
+ */
+int lmi_nms_decode(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres,
+                   void *workspace, int64_t workspace_bytes, void *stream);
+int lmi_nms_suppress(const float *pred, int batch, int nc, int nm, int anchors, double iou_thres,
+                     int agnostic, int max_det, int max_nms, float max_wh, int rotated,
+                     float *out_det, int32_t *out_count, int32_t *out_anchor, void *workspace,
+                     int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Finalize -- replaces, per image, `ops.scale_boxes(img.shape[2:], pred[:, :4], orig_img.shape)`

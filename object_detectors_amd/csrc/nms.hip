@@ -685,41 +685,63 @@ int64_t lmi_nms_workspace_bytes(int batch, int anchors) {
   return (int64_t)nms_layout(batch, anchors).total;
 }
 
-static int nms_common(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres, double iou_thres,
-                      int agnostic, int max_det, int max_nms, float max_wh, float *out_det, int32_t *out_count,
-                      int32_t *out_anchor, void *workspace, int64_t workspace_bytes, void *stream, int rotated) {
-  LMI_REQUIRE(pred && out_det && out_count && out_anchor && workspace, LMI_ERR_BAD_ARG, "lmi_nms_v8: NULL pointer");
+struct NmsCall {
+  NmsLayout L;
+  hipStream_t s;
+  int *cand_count;
+  uint64_t *keys;
+  int *cls_of;
+  float4 *sbox;
+  unsigned char *ws;
+};
+
+static int nms_check(const float *pred, int batch, int nc, int nm, int anchors, void *workspace, int64_t workspace_bytes,
+                     void *stream, NmsCall &C) {
+  LMI_REQUIRE(pred && workspace, LMI_ERR_BAD_ARG, "lmi_nms_v8: NULL pointer");
   LMI_REQUIRE(batch > 0 && batch <= 65535 && nc > 0 && nm >= 0 && anchors > 0, LMI_ERR_BAD_ARG,
               "lmi_nms_v8: bad shape batch=%d nc=%d nm=%d anchors=%d", batch, nc, nm, anchors);
   LMI_REQUIRE(anchors <= (1 << 24), LMI_ERR_LIMIT, "lmi_nms_v8: anchors %d > 2^24", anchors);
+  LMI_REQUIRE(lmi_is_aligned(pred, 16) && lmi_is_aligned(workspace, 256), LMI_ERR_ALIGNMENT,
+              "lmi_nms_v8: pred must be 16-byte and workspace 256-byte aligned");
+  C.L = nms_layout(batch, anchors);
+  LMI_REQUIRE(workspace_bytes >= (int64_t)C.L.total, LMI_ERR_WORKSPACE, "lmi_nms_v8: workspace %lld < %lld bytes",
+              (long long)workspace_bytes, (long long)C.L.total);
+  C.s = reinterpret_cast<hipStream_t>(stream);
+  C.ws = reinterpret_cast<unsigned char *>(workspace);
+  C.cand_count = reinterpret_cast<int *>(C.ws + C.L.off_count);
+  C.keys = reinterpret_cast<uint64_t *>(C.ws + C.L.off_keys);
+  C.cls_of = reinterpret_cast<int *>(C.ws + C.L.off_cls);
+  C.sbox = reinterpret_cast<float4 *>(C.ws + C.L.off_sbox);
+  return LMI_OK;
+}
+
+static int nms_check_suppress(const float *out_det, const int32_t *out_count, const int32_t *out_anchor, double iou_thres,
+                              int max_det, int max_nms) {
+  LMI_REQUIRE(out_det && out_count && out_anchor, LMI_ERR_BAD_ARG, "lmi_nms_v8: NULL pointer");
   LMI_REQUIRE(max_det > 0 && max_det <= LMI_MAX_DET_CAP, LMI_ERR_LIMIT, "lmi_nms_v8: max_det %d not in 1..%d", max_det, LMI_MAX_DET_CAP);
   LMI_REQUIRE(max_nms > 0, LMI_ERR_BAD_ARG, "lmi_nms_v8: max_nms must be positive");
   LMI_REQUIRE(iou_thres >= 0.0 && iou_thres <= 1.0, LMI_ERR_BAD_ARG, "lmi_nms_v8: Invalid IoU %f, valid values are between 0.0 and 1.0", iou_thres);
-  LMI_REQUIRE(lmi_is_aligned(pred, 16) && lmi_is_aligned(workspace, 256) && lmi_is_aligned(out_det, 4), LMI_ERR_ALIGNMENT,
-              "lmi_nms_v8: pred must be 16-byte and workspace 256-byte aligned");
-  const NmsLayout L = nms_layout(batch, anchors);
-  LMI_REQUIRE(workspace_bytes >= (int64_t)L.total, LMI_ERR_WORKSPACE, "lmi_nms_v8: workspace %lld < %lld bytes",
-              (long long)workspace_bytes, (long long)L.total);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
-  int *cand_count = reinterpret_cast<int *>(ws + L.off_count);
-  uint64_t *keys = reinterpret_cast<uint64_t *>(ws + L.off_keys);
-  int *cls_of = reinterpret_cast<int *>(ws + L.off_cls);
-  float4 *sbox = reinterpret_cast<float4 *>(ws + L.off_sbox);
+  LMI_REQUIRE(lmi_is_aligned(out_det, 4), LMI_ERR_ALIGNMENT, "lmi_nms_v8: out_det must be 4-byte aligned");
+  return LMI_OK;
+}
 
-  hipError_t e = hipMemsetAsync(cand_count, 0, sizeof(int) * (size_t)batch, s);
+// first half: candidate filter (HBM-bound, reads the head once)
+static int nms_decode(const NmsCall &C, const float *pred, int batch, int nc, int nm, int anchors, float conf_thres) {
+  hipError_t e = hipMemsetAsync(C.cand_count, 0, sizeof(int) * (size_t)batch, C.s);
   if (e != hipSuccess) { lmi_set_error("lmi_nms_v8: hipMemsetAsync: %s", hipGetErrorString(e)); return LMI_ERR_LAUNCH; }
-
   if ((anchors & 3) == 0) {
     dim3 grid((anchors / 4 + 63) / 64, batch);
-    hipLaunchKernelGGL(nms_decode_filter<4>, grid, dim3(256), 0, s, pred, nc, nm, anchors, conf_thres, keys, L.P, cls_of, cand_count);
+    hipLaunchKernelGGL(nms_decode_filter<4>, grid, dim3(256), 0, C.s, pred, nc, nm, anchors, conf_thres, C.keys, C.L.P, C.cls_of, C.cand_count);
   } else {
     dim3 grid((anchors + 63) / 64, batch);
-    hipLaunchKernelGGL(nms_decode_filter<1>, grid, dim3(256), 0, s, pred, nc, nm, anchors, conf_thres, keys, L.P, cls_of, cand_count);
+    hipLaunchKernelGGL(nms_decode_filter<1>, grid, dim3(256), 0, C.s, pred, nc, nm, anchors, conf_thres, C.keys, C.L.P, C.cls_of, C.cand_count);
   }
-  int rc = lmi_check_launch("nms_decode_filter");
-  if (rc) return rc;
+  return lmi_check_launch("nms_decode_filter");
+}
 
+// second half: sort + suppression, one workgroup per image (latency / LDS-bound, next to no HBM traffic)
+static int nms_suppress(const NmsCall &C, const float *pred, int batch, int nc, int nm, int anchors, double iou_thres, int agnostic,
+                        int max_det, int max_nms, float max_wh, float *out_det, int32_t *out_count, int32_t *out_anchor, int rotated) {
   // torchvision compares the fp32 IoU against the threshold as a double: use the largest fp32 <= thr.
   // nms_rotated compares `ious.max(0) < threshold` in fp32 (tensor vs Python float): the threshold rounded to fp32.
   float thr = (float)iou_thres;
@@ -727,25 +749,57 @@ static int nms_common(const float *pred, int batch, int nc, int nm, int anchors,
 
   SortNmsParams S;
   S.pred = pred; S.nc = nc; S.nm = nm; S.A = anchors; S.iou_thr = thr; S.agnostic = agnostic ? 1 : 0;
-  S.max_det = max_det; S.max_nms = max_nms; S.max_wh = max_wh; S.keys = keys; S.P = L.P; S.cls_of = cls_of;
-  S.sbox = sbox; S.cand_count = cand_count; S.out_det = out_det; S.out_count = out_count; S.out_anchor = out_anchor;
-  S.lds_keys = L.P < kSortLdsCap ? L.P : kSortLdsCap;
-  S.scd = reinterpret_cast<float2 *>(ws + L.off_cd);
+  S.max_det = max_det; S.max_nms = max_nms; S.max_wh = max_wh; S.keys = C.keys; S.P = C.L.P; S.cls_of = C.cls_of;
+  S.sbox = C.sbox; S.cand_count = C.cand_count; S.out_det = out_det; S.out_count = out_count; S.out_anchor = out_anchor;
+  S.lds_keys = C.L.P < kSortLdsCap ? C.L.P : kSortLdsCap;
+  S.scd = reinterpret_cast<float2 *>(C.ws + C.L.off_cd);
   if (rotated) {
     LMI_REQUIRE(nm >= 1, LMI_ERR_BAD_ARG, "lmi_nms_v8_rotated: the angle must be the last of nm >= 1 extra channels");
     const size_t head = (size_t)S.lds_keys * 8 + 4 * (size_t)((max_det + 1) & ~1) + 4 * 17 + 16;
     S.lbox_off = (int)((head + 15) & ~(size_t)15);
     const size_t lds_rot = (size_t)S.lbox_off + (size_t)S.lds_keys * (16 + 8);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_rotated), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(nms_sort_rotated, dim3(batch), dim3(kSortThreads), lds_rot, s, S);
+    hipLaunchKernelGGL(nms_sort_rotated, dim3(batch), dim3(kSortThreads), lds_rot, C.s, S);
     return lmi_check_launch("nms_sort_rotated");
   }
   const size_t lds_small = (size_t)S.lds_keys * 8 + 4 * 6 * (size_t)((max_det + 1) & ~1) + 64 * 8 + 64 * 4 + 16;
   S.lbox_off = (int)((lds_small + 15) & ~(size_t)15);
   const size_t lds = (size_t)S.lbox_off + (size_t)S.lds_keys * 16;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_suppress), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(nms_sort_suppress, dim3(batch), dim3(kSortThreads), lds, s, S);
+  hipLaunchKernelGGL(nms_sort_suppress, dim3(batch), dim3(kSortThreads), lds, C.s, S);
   return lmi_check_launch("nms_sort_suppress");
+}
+
+static int nms_common(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres, double iou_thres,
+                      int agnostic, int max_det, int max_nms, float max_wh, float *out_det, int32_t *out_count,
+                      int32_t *out_anchor, void *workspace, int64_t workspace_bytes, void *stream, int rotated) {
+  NmsCall C;
+  int rc = nms_check(pred, batch, nc, nm, anchors, workspace, workspace_bytes, stream, C);
+  if (rc) return rc;
+  rc = nms_check_suppress(out_det, out_count, out_anchor, iou_thres, max_det, max_nms);
+  if (rc) return rc;
+  rc = nms_decode(C, pred, batch, nc, nm, anchors, conf_thres);
+  if (rc) return rc;
+  return nms_suppress(C, pred, batch, nc, nm, anchors, iou_thres, agnostic, max_det, max_nms, max_wh, out_det, out_count, out_anchor, rotated);
+}
+
+int lmi_nms_decode(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres, void *workspace,
+                   int64_t workspace_bytes, void *stream) {
+  NmsCall C;
+  int rc = nms_check(pred, batch, nc, nm, anchors, workspace, workspace_bytes, stream, C);
+  if (rc) return rc;
+  return nms_decode(C, pred, batch, nc, nm, anchors, conf_thres);
+}
+
+int lmi_nms_suppress(const float *pred, int batch, int nc, int nm, int anchors, double iou_thres, int agnostic, int max_det,
+                     int max_nms, float max_wh, int rotated, float *out_det, int32_t *out_count, int32_t *out_anchor,
+                     void *workspace, int64_t workspace_bytes, void *stream) {
+  NmsCall C;
+  int rc = nms_check(pred, batch, nc, nm, anchors, workspace, workspace_bytes, stream, C);
+  if (rc) return rc;
+  rc = nms_check_suppress(out_det, out_count, out_anchor, iou_thres, max_det, max_nms);
+  if (rc) return rc;
+  return nms_suppress(C, pred, batch, nc, nm, anchors, iou_thres, agnostic, max_det, max_nms, max_wh, out_det, out_count, out_anchor, rotated ? 1 : 0);
 }
 
 int lmi_nms_v8(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres, double iou_thres,

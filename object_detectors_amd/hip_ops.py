@@ -175,9 +175,13 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
 
 
 def nms_v8(pred: torch.Tensor, conf_thres: float, iou_thres: float = 0.45, agnostic: bool = False, max_det: int = 300,
-           nc: int = 0, max_nms: int = 30000, max_wh: float = 7680.0, out=None, rotated: bool = False):
+           nc: int = 0, max_nms: int = 30000, max_wh: float = 7680.0, out=None, rotated: bool = False,
+           decode_done: Optional[torch.cuda.Event] = None):
     """`ops.non_max_suppression` on the head output (B, 4+nc+nm, A) fp32.  rotated=True: oriented boxes
     (xywh + angle as the last extra channel, ultralytics' nms_rotated on probiou), rows stay xywh.
+    decode_done: an event recorded on the current stream between the candidate filter (HBM-bound) and the
+    sort + suppression pass (latency-bound): work on another stream that waits for it shares the chip with the
+    latter (lmi_nms_decode / lmi_nms_suppress instead of the one-call lmi_nms_v8; same result).
 
     Returns (det (B,max_det,6+nm) fp32, count (B,) int32, anchor (B,max_det) int32), all on the
     device; rows >= count[b] are unspecified.  `out` = a previous result tuple of the same shapes
@@ -202,6 +206,13 @@ def nms_v8(pred: torch.Tensor, conf_thres: float, iou_thres: float = 0.45, agnos
         anchor = torch.empty((b, max_det), dtype=torch.int32, device=pred.device)
     nbytes = int(_L.lmi_nms_workspace_bytes(b, a))
     ws = _ws.get(pred.device, "nms", nbytes)
+    if decode_done is not None:
+        check(_L.lmi_nms_decode(pred.data_ptr(), b, nc, nm, a, float(conf_thres), ws.data_ptr(), ws.numel(), _stream()))
+        decode_done.record()
+        check(_L.lmi_nms_suppress(pred.data_ptr(), b, nc, nm, a, float(iou_thres), int(agnostic), int(max_det), int(max_nms),
+                                  float(max_wh), int(rotated), det.data_ptr(), count.data_ptr(), anchor.data_ptr(), ws.data_ptr(),
+                                  ws.numel(), _stream()))
+        return det, count, anchor
     fn = _L.lmi_nms_v8_rotated if rotated else _L.lmi_nms_v8
     check(fn(pred.data_ptr(), b, nc, nm, a, float(conf_thres), float(iou_thres), int(agnostic), int(max_det),
              int(max_nms), float(max_wh), det.data_ptr(), count.data_ptr(), anchor.data_ptr(), ws.data_ptr(),

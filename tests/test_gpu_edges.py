@@ -188,3 +188,30 @@ def test_process_mask_random_shapes(ops):
             assert g.shape == ref.shape, tag
             diff = (g != ref).sum()
             assert diff <= max(3, 0.001 * ref.sum()), f"{tag}: {diff} pixels differ of {int(ref.sum())} set"
+
+
+@pytest.mark.parametrize("rotated", [False, True])
+def test_nms_halves_equal_the_one_call_form(ops, rotated):
+    """lmi_nms_decode + lmi_nms_suppress (hip_ops.nms_v8(decode_done=event)) against lmi_nms_v8[_rotated], with work
+    on a second stream started from the event between the halves, as bench.py schedules the letterbox."""
+    rng = np.random.default_rng(31)
+    nc, nm = (15, 1) if rotated else (80, 32)
+    head = synth.head(rng, 4, nc, nm, 640, 30)
+    if rotated:
+        head[:, 4 + nc] = rng.uniform(-0.7, 2.2, head[:, 4 + nc].shape)
+    pred = torch.from_numpy(head).cuda()
+    one = ops.nms_v8(pred.clone(), 0.25, 0.45, nc=nc, rotated=rotated)
+    ev, side = torch.cuda.Event(), torch.cuda.Stream()
+    frames = torch.from_numpy(rng.integers(0, 256, (2, 270, 480, 3), dtype=np.uint8)).cuda()
+    torch.cuda.synchronize()
+    two = ops.nms_v8(pred.clone(), 0.25, 0.45, nc=nc, rotated=rotated, decode_done=ev)
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        lb, _ = ops.letterbox(frames, (160, 160))
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(one[1], two[1]) and int(one[1].sum()) > 0
+    for b, c in enumerate(one[1].tolist()):
+        assert torch.equal(one[0][b, :c], two[0][b, :c]) and torch.equal(one[2][b, :c], two[2][b, :c])
+    want, _ = OC.letterbox_u8(frames[1].cpu().numpy(), 160, 160)
+    assert np.array_equal(lb[1].cpu().numpy(), want)
