@@ -96,10 +96,7 @@ class Pipeline:
             self.side.wait_event(self.decode_done)
             with torch.cuda.stream(self.side):
                 self._letterbox(time_letterbox)
-        out = self._post(time_upsample)
-        if fork:
-            main.wait_stream(self.side)
-        return out
+        return self._post(time_upsample, join=(lambda: main.wait_stream(self.side)) if fork else None)
 
     def _letterbox(self, time_letterbox):
         if time_letterbox is not None:
@@ -108,17 +105,23 @@ class Pipeline:
         if time_letterbox is not None:
             time_letterbox[1].record()
 
-    def _post(self, time_upsample=None):
+    def _post(self, time_upsample=None, join=None):
         ops, cfg = self.ops, self.cfg
         det, count, anchor = self.nms_out
         self.fin_out = fin = ops.finalize_detections(det, count, cfg["nc"], (self.S, self.S), (cfg["h"], cfg["w"]), MASK_CONF, out=self.fin_out)
         masks = None
+        if join is not None and self.proto is None:
+            join()
         if self.proto is not None:
             if self.mask_out is None:  # first pass: size the mask buffer from the (deterministic) survivor count
                 self.capacity = int(fin["slot_base"][-1].item())
                 self.mask_out = torch.empty((max(self.capacity, 1), cfg["h"], cfg["w"]), dtype=torch.uint8, device=self.frames.device)
             masks, ovf = ops.process_mask(self.proto, det, fin["slot_map"], fin["slot_base"], (cfg["h"], cfg["w"]),
-                                          self.capacity, torch.uint8, out=self.mask_out, split_events=time_upsample)
+                                          self.capacity, torch.uint8, out=self.mask_out, split_events=time_upsample,
+                                          # the side stream joins BEFORE the upsample: nothing may run beside the zero fill of
+                                          # the masks, whose write pattern collapses under concurrent traffic
+                                          # (profiles/r01/write_ceiling.md)
+                                          before_upsample=join)
         return det, count, anchor, fin, masks
 
 

@@ -614,70 +614,103 @@ int lmi_mask_logits(const float *proto, int batch, int nm, int mh, int mw, const
   return lmi_check_launch("mask_gemm_kernel");
 }
 
+namespace {
+
+struct UpCall {
+  UpParams U;
+  MaskGeom g;
+  hipStream_t s;
+  int px;       // pixels per 16-byte chunk
+  bool split;   // rows are whole chunks: zero fill + box pass
+};
+
+int up_setup(const char *fn, void *workspace, int batch, int nm, int mh, int mw, const float *det, int max_det, int det_stride,
+             const int32_t *slot_map, const int32_t *slot_base, int h0, int w0, void *out_masks, int out_dtype,
+             int64_t capacity_masks, int32_t *overflow, void *stream, UpCall &C) {
+  LMI_REQUIRE(workspace && det && slot_map && slot_base && out_masks, LMI_ERR_BAD_ARG, "%s: NULL pointer", fn);
+  int rc = mask_check_common(fn, batch, nm, mh, mw, h0, w0, max_det, det_stride, capacity_masks, C.g);
+  if (rc) return rc;
+  LMI_REQUIRE(out_dtype == LMI_U8 || out_dtype == LMI_F32, LMI_ERR_BAD_ARG, "%s: out_dtype must be LMI_U8 or LMI_F32", fn);
+  LMI_REQUIRE(lmi_is_aligned(out_masks, 16) && lmi_is_aligned(workspace, 256), LMI_ERR_ALIGNMENT,
+              "%s: out_masks must be 16-byte and workspace 256-byte aligned", fn);
+  UpParams &U = C.U;
+  U.det = det; U.slot_map = slot_map; U.slot_base = slot_base; U.logits = reinterpret_cast<const float *>(workspace); U.out = out_masks;
+  U.batch = batch; U.max_det = max_det; U.det_stride = det_stride; U.capacity = capacity_masks; U.g = C.g; U.overflow = overflow;
+  U.table = reinterpret_cast<int4 *>(reinterpret_cast<char *>(workspace) + align_up((size_t)capacity_masks * mh * mw * sizeof(float), 256));
+  U.rows_per_block = 0; U.lds_rows = 0;
+  C.s = reinterpret_cast<hipStream_t>(stream);
+  C.px = out_dtype == LMI_U8 ? 16 : 4;
+  C.split = (w0 % C.px) == 0;
+  return LMI_OK;
+}
+
+// rows per strip: the largest power of two <= start whose staged logits rows fit 48 KiB of LDS
+int up_strip(UpCall &C, int start, int extra_cols) {
+  const int wh = C.g.bottom - C.g.top, ww = C.g.right - C.g.left;
+  int rpb = start, lds_rows = 0;
+  for (;; rpb >>= 1) {
+    lds_rows = (int)((double)rpb * (double)wh / (double)C.g.h0) + 3;
+    if (lds_rows > wh) lds_rows = wh;
+    if ((size_t)lds_rows * (ww + extra_cols) * sizeof(float) <= 48 * 1024 || rpb == 1) break;
+  }
+  if ((size_t)lds_rows * (ww + extra_cols) * sizeof(float) > 64 * 1024) {
+    lmi_set_error("lmi_mask_upsample: prototype rows too wide for LDS (%d)", ww);
+    return LMI_ERR_LIMIT;
+  }
+  C.U.rows_per_block = rpb; C.U.lds_rows = lds_rows;
+  return LMI_OK;
+}
+
+// zeros for every live slot at the memset rate: one workgroup per CU, the compact write window (see the kernel)
+int up_fill(const int32_t *slot_base, int batch, int h0, int w0, int px, void *out_masks, int64_t capacity_masks, int32_t *overflow,
+            hipStream_t s) {
+  int ncu = 256, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+    ncu = 256;
+  hipLaunchKernelGGL(mask_zero_fill_kernel, dim3(ncu), dim3(256), 0, s, slot_base, batch, (long long)capacity_masks,
+                     (long long)h0 * (w0 / px), reinterpret_cast<uint4 *>(out_masks), overflow);
+  return lmi_check_launch("mask_zero_fill_kernel");
+}
+
+// the chunks that meet a box; ALU-bound, not store-bound: tall strips, so that a lane's horizontal taps serve many rows
+int up_boxes(UpCall &C, int out_dtype) {
+  hipLaunchKernelGGL(mask_slot_table_kernel, dim3((unsigned)((C.U.capacity + 255) / 256)), dim3(256), 0, C.s, C.U, const_cast<int4 *>(C.U.table));
+  int rc = up_strip(C, 256, 1);
+  if (rc) return rc;
+  const size_t lds = (size_t)C.U.lds_rows * (C.g.right - C.g.left + 1) * sizeof(float);
+  dim3 grid((C.g.h0 + C.U.rows_per_block - 1) / C.U.rows_per_block, (unsigned)C.U.capacity);
+  if (out_dtype == LMI_U8)
+    hipLaunchKernelGGL(mask_box_kernel<uint8_t>, grid, dim3(256), lds, C.s, C.U);
+  else
+    hipLaunchKernelGGL(mask_box_kernel<float>, grid, dim3(256), lds, C.s, C.U);
+  return lmi_check_launch("mask_box_kernel");
+}
+
+}  // namespace
+
 int lmi_mask_upsample(void *workspace, int batch, int nm, int mh, int mw, const float *det, int max_det, int det_stride,
                       const int32_t *slot_map, const int32_t *slot_base, int h0, int w0, void *out_masks, int out_dtype,
                       int64_t capacity_masks, int32_t *overflow, void *stream) {
-  LMI_REQUIRE(workspace && det && slot_map && slot_base && out_masks, LMI_ERR_BAD_ARG, "lmi_mask_upsample: NULL pointer");
-  MaskGeom g;
-  int rc = mask_check_common("lmi_mask_upsample", batch, nm, mh, mw, h0, w0, max_det, det_stride, capacity_masks, g);
+  UpCall C;
+  int rc = up_setup("lmi_mask_upsample", workspace, batch, nm, mh, mw, det, max_det, det_stride, slot_map, slot_base, h0, w0, out_masks,
+                    out_dtype, capacity_masks, overflow, stream, C);
   if (rc) return rc;
-  LMI_REQUIRE(out_dtype == LMI_U8 || out_dtype == LMI_F32, LMI_ERR_BAD_ARG, "lmi_mask_upsample: out_dtype must be LMI_U8 or LMI_F32");
-  LMI_REQUIRE(lmi_is_aligned(out_masks, 16) && lmi_is_aligned(workspace, 256), LMI_ERR_ALIGNMENT,
-              "lmi_mask_upsample: out_masks must be 16-byte and workspace 256-byte aligned");
-  const int wh = g.bottom - g.top, ww = g.right - g.left;
-  UpParams U;
-  U.det = det; U.slot_map = slot_map; U.slot_base = slot_base; U.logits = reinterpret_cast<const float *>(workspace); U.out = out_masks;
-  U.batch = batch; U.max_det = max_det; U.det_stride = det_stride; U.capacity = capacity_masks; U.g = g; U.overflow = overflow;
-  // rows per strip: as many as keep the staged logits rows within 48 KiB of LDS
-  int rpb = 16;
-  int lds_rows = 0;
-  for (;; rpb >>= 1) {
-    lds_rows = (int)((double)rpb * (double)wh / (double)h0) + 3;
-    if (lds_rows > wh) lds_rows = wh;
-    if ((size_t)lds_rows * ww * sizeof(float) <= 48 * 1024 || rpb == 1) break;
-  }
-  LMI_REQUIRE((size_t)lds_rows * ww * sizeof(float) <= 64 * 1024, LMI_ERR_LIMIT, "lmi_mask_upsample: prototype rows too wide for LDS (%d)", ww);
-  U.rows_per_block = rpb; U.lds_rows = lds_rows;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // Split path (rows are whole 16-byte chunks): zeros for every live slot at the memset rate, then mask_box_kernel
   // overwrites only the chunks that meet a box.  LMI_MASK_UPSAMPLE=single keeps the one-kernel path (measurement).
-  const int px = out_dtype == LMI_U8 ? 16 : 4;
   const char *single = getenv("LMI_MASK_UPSAMPLE");
-  const bool split = (w0 % px) == 0 && !(single && strcmp(single, "single") == 0);
-  U.table = nullptr;
-  if (split) {
-    int4 *table = reinterpret_cast<int4 *>(reinterpret_cast<char *>(workspace) + align_up((size_t)capacity_masks * mh * mw * sizeof(float), 256));
-    U.table = table;
-    hipLaunchKernelGGL(mask_slot_table_kernel, dim3((unsigned)((capacity_masks + 255) / 256)), dim3(256), 0, s, U, table);
-    int ncu = 256, dev = 0;   // one workgroup per CU: the compact write window (see the kernel)
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
-      ncu = 256;
-    hipLaunchKernelGGL(mask_zero_fill_kernel, dim3(ncu), dim3(256), 0, s, slot_base, batch, (long long)capacity_masks,
-                       (long long)h0 * (w0 / px), reinterpret_cast<uint4 *>(out_masks), overflow);
-    int rc2 = lmi_check_launch("mask_zero_fill_kernel");
-    if (rc2) return rc2;
-    // the box pass is ALU-bound, not store-bound: tall strips, so that a lane's horizontal taps serve many rows
-    rpb = 256;
-    for (;; rpb >>= 1) {
-      lds_rows = (int)((double)rpb * (double)wh / (double)h0) + 3;
-      if (lds_rows > wh) lds_rows = wh;
-      if ((size_t)lds_rows * (ww + 1) * sizeof(float) <= 48 * 1024 || rpb == 1) break;
-    }
-    U.rows_per_block = rpb; U.lds_rows = lds_rows;
+  if (C.split && !(single && strcmp(single, "single") == 0)) {
+    rc = up_fill(slot_base, batch, h0, w0, C.px, out_masks, capacity_masks, overflow, C.s);
+    if (rc) return rc;
+    return up_boxes(C, out_dtype);
   }
-  const size_t lds = (size_t)lds_rows * (ww + (split ? 1 : 0)) * sizeof(float);
-  dim3 ugrid((h0 + rpb - 1) / rpb, (unsigned)capacity_masks);
-  if (split) {
-    if (out_dtype == LMI_U8)
-      hipLaunchKernelGGL(mask_box_kernel<uint8_t>, ugrid, dim3(256), lds, s, U);
-    else
-      hipLaunchKernelGGL(mask_box_kernel<float>, ugrid, dim3(256), lds, s, U);
-    return lmi_check_launch("mask_box_kernel");
-  }
+  rc = up_strip(C, 16, 0);
+  if (rc) return rc;
+  const size_t lds = (size_t)C.U.lds_rows * (C.g.right - C.g.left) * sizeof(float);
+  dim3 ugrid((h0 + C.U.rows_per_block - 1) / C.U.rows_per_block, (unsigned)capacity_masks);
   if (out_dtype == LMI_U8)
-    hipLaunchKernelGGL(mask_upsample_kernel<uint8_t>, ugrid, dim3(256), lds, s, U);
+    hipLaunchKernelGGL(mask_upsample_kernel<uint8_t>, ugrid, dim3(256), lds, C.s, C.U);
   else
-    hipLaunchKernelGGL(mask_upsample_kernel<float>, ugrid, dim3(256), lds, s, U);
+    hipLaunchKernelGGL(mask_upsample_kernel<float>, ugrid, dim3(256), lds, C.s, C.U);
   return lmi_check_launch("mask_upsample_kernel");
 }
 

@@ -310,12 +310,14 @@ def scale_coords(det: torch.Tensor, count: torch.Tensor, nkpt: int, ndim: int, m
 
 def process_mask(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.Tensor, slot_base: torch.Tensor,
                  orig_hw: Tuple[int, int], capacity: int, out_dtype: torch.dtype = torch.uint8,
-                 out: Optional[torch.Tensor] = None, split_events=None):
+                 out: Optional[torch.Tensor] = None, split_events=None, before_upsample=None):
     """`process_mask_native` + `masks[M]` for the whole batch (uniform original size).
 
     Returns (masks (capacity,H0,W0) of uint8|float32 in slot order, overflow (1,) int32).
-    split_events: optional (start, end) torch.cuda.Event pair recorded around the upsample kernel
-    alone (the two halves are then enqueued through lmi_mask_logits / lmi_mask_upsample)."""
+    split_events: optional (start, end) torch.cuda.Event pair recorded around the upsample stage
+    alone (the two halves are then enqueued through lmi_mask_logits / lmi_mask_upsample).
+    before_upsample: optional callable run between the two halves (e.g. joining another stream: nothing should run
+    beside the upsample's zero fill, see profiles/r01/write_ceiling.md)."""
     _need_cuda(proto, "proto")
     if proto.dtype != torch.float32:
         proto = proto.float()
@@ -331,17 +333,21 @@ def process_mask(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.Tensor,
     overflow = torch.empty((1,), dtype=torch.int32, device=proto.device)
     nbytes = int(_L.lmi_mask_workspace_bytes(capacity, mh, mw))
     ws = _ws.get(proto.device, "mask", nbytes)
-    if split_events is None:
+    if split_events is None and before_upsample is None:
         check(_L.lmi_process_mask(proto.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
                                   slot_base.data_ptr(), h0, w0, out.data_ptr(), ldt, capacity, overflow.data_ptr(),
                                   ws.data_ptr(), ws.numel(), _stream()))
     else:
         check(_L.lmi_mask_logits(proto.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
                                  slot_base.data_ptr(), h0, w0, capacity, ws.data_ptr(), ws.numel(), _stream()))
-        split_events[0].record()
+        if before_upsample is not None:
+            before_upsample()
+        if split_events is not None:
+            split_events[0].record()
         check(_L.lmi_mask_upsample(ws.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
                                    slot_base.data_ptr(), h0, w0, out.data_ptr(), ldt, capacity, overflow.data_ptr(), _stream()))
-        split_events[1].record()
+        if split_events is not None:
+            split_events[1].record()
     return out, overflow
 
 
