@@ -238,9 +238,10 @@ int lmi_scale_coords(float *det, const int32_t *count, int batch, int max_det, i
  *              their number is written to overflow[0] ([device] int32, may be NULL)
  *   workspace  [device] >= lmi_mask_workspace_bytes(capacity_masks, mh, mw), 256-byte aligned
  * Only uniform originals (every image H0 x W0) are supported by this entry.
- * lmi_process_mask = lmi_mask_logits (the coefficient x prototype product into `workspace`) followed by
- * lmi_mask_upsample (crop + bilinear + box crop + threshold from `workspace`); the two halves are
- * exported so a caller can time or schedule them separately.
+ * lmi_process_mask = lmi_mask_logits (the coefficient x prototype product, and one box record per slot, into
+ * `workspace`) followed by lmi_mask_upsample (crop + bilinear + box crop + threshold from the `workspace`
+ * lmi_mask_logits left, same arguments); the two halves are exported so a caller can time or schedule
+ * them separately.
  */
 int64_t lmi_mask_workspace_bytes(int64_t capacity_masks, int mh, int mw);
 int lmi_mask_logits(const float *proto, int batch, int nm, int mh, int mw, const float *det,

@@ -45,6 +45,7 @@ struct GemmParams {
   long long capacity;
   MaskGeom g;
   int tiles_per_block;  // pixel tiles (32*V px) per wave
+  int4 *table;          // per-slot pixel ranges of the box {xa, xb, ya, yb} for mask_box_kernel
 };
 
 // aten upsample_bilinear2d, align_corners=False: source index / weights of output index d
@@ -55,6 +56,16 @@ __device__ __forceinline__ void bilinear_src(float scale, int d, int in_n, int &
   i1 = i0 + ((i0 < in_n - 1) ? 1 : 0);
   l1 = s - (float)i0;
   l0 = 1.0f - l1;
+}
+
+// Integer pixel ranges of a box: x >= x1 && x < x2  <=>  ceil(x1) <= x < ceil(x2) for integer x (same for y),
+// clamped to the frame; all zero when the box holds no pixel (NaN included).
+__device__ __forceinline__ int4 box_ranges(float bx1, float by1, float bx2, float by2, int H0, int W0) {
+  if (!(bx1 < bx2 && by1 < by2)) return make_int4(0, 0, 0, 0);
+  const int xa = (int)ceilf(fminf(fmaxf(bx1, 0.0f), (float)W0)), xb = (int)ceilf(fminf(fmaxf(bx2, 0.0f), (float)W0));
+  const int ya = (int)ceilf(fminf(fmaxf(by1, 0.0f), (float)H0)), yb = (int)ceilf(fminf(fmaxf(by2, 0.0f), (float)H0));
+  if (xa >= xb || ya >= yb) return make_int4(0, 0, 0, 0);
+  return make_int4(xa, xb, ya, yb);
 }
 
 // grid: x = pixel-tile groups, y = survivor tile (32 slots), z = image
@@ -230,9 +241,12 @@ __global__ __launch_bounds__(256) void mask_logits_rows_kernel(GemmParams G) {
     }
     if (threadIdx.x < ns) {
       int lo, hi;
-      row_range(G.det + (size_t)G.slot_map[base + s0 + threadIdx.x] * G.det_stride, lo, hi);
+      const float *d = G.det + (size_t)G.slot_map[base + s0 + threadIdx.x] * G.det_stride;
+      row_range(d, lo, hi);
       rlo[threadIdx.x] = lo;
       rhi[threadIdx.x] = hi;
+      const long long slot = (long long)base + s0 + threadIdx.x;   // the upsample's box pass reads this record
+      if (blockIdx.x == 0 && slot < G.capacity) G.table[slot] = box_ranges(d[0], d[1], d[2], d[3], G.g.h0, G.g.w0);
     }
     __syncthreads();
 
@@ -316,24 +330,13 @@ struct MaskOut<float> {
   static __device__ __forceinline__ void store1(float *p, bool on) { *p = on ? 1.0f : 0.0f; }
 };
 
-// Integer pixel ranges of a box: x >= x1 && x < x2  <=>  ceil(x1) <= x < ceil(x2) for integer x (same for y),
-// clamped to the frame; all zero when the box holds no pixel (NaN included).
-__device__ __forceinline__ int4 box_ranges(float bx1, float by1, float bx2, float by2, int H0, int W0) {
-  if (!(bx1 < bx2 && by1 < by2)) return make_int4(0, 0, 0, 0);
-  const int xa = (int)ceilf(fminf(fmaxf(bx1, 0.0f), (float)W0)), xb = (int)ceilf(fminf(fmaxf(bx2, 0.0f), (float)W0));
-  const int ya = (int)ceilf(fminf(fmaxf(by1, 0.0f), (float)H0)), yb = (int)ceilf(fminf(fmaxf(by2, 0.0f), (float)H0));
-  if (xa >= xb || ya >= yb) return make_int4(0, 0, 0, 0);
-  return make_int4(xa, xb, ya, yb);
-}
-
-// one record per slot {xa, xb, ya, yb}: lets the box-only strip kernel decide with ONE load whether it has work
-__global__ __launch_bounds__(256) void mask_slot_table_kernel(UpParams U, int4 *table) {
+// one record per live slot {xa, xb, ya, yb}: lets mask_box_kernel decide with one load whether a strip has work.
+// mask_logits_rows_kernel writes the records itself; this kernel serves the MFMA variant of the logits.
+__global__ __launch_bounds__(256) void mask_slot_table_kernel(GemmParams G) {
   const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (s >= U.capacity) return;
-  const long long total = min((long long)U.slot_base[U.batch], U.capacity);
-  if (s >= total) { table[s] = make_int4(0, 0, 0, 0); return; }   // dead slot: no rows, the strip kernel leaves at once
-  const float *d = U.det + (size_t)U.slot_map[s] * U.det_stride;
-  table[s] = box_ranges(d[0], d[1], d[2], d[3], U.g.h0, U.g.w0);
+  if (s >= min((long long)G.slot_base[G.batch], G.capacity)) return;
+  const float *d = G.det + (size_t)G.slot_map[s] * G.det_stride;
+  G.table[s] = box_ranges(d[0], d[1], d[2], d[3], G.g.h0, G.g.w0);
 }
 
 // Zeros for every live slot, written the way that reaches the memset rate on MI355X (profiles/r01/write_ceiling.md):
@@ -369,7 +372,8 @@ __global__ __launch_bounds__(256) void mask_box_kernel(UpParams U) {
   float *L = reinterpret_cast<float *>(smem);
 
   const long long slot = blockIdx.y;
-  const int4 t = U.table[slot];   // zeros beyond the live slots and for boxes that hold no pixel
+  if (slot >= U.slot_base[U.batch]) return;   // beyond the live slots (the grid spans the buffer's capacity)
+  const int4 t = U.table[slot];               // all zero for a box that holds no pixel
   const int ra = max((int)blockIdx.x * U.rows_per_block, t.z), rb = min(((int)blockIdx.x + 1) * U.rows_per_block, t.w);
   if (ra >= rb) return;           // most workgroups: no row of the box in this strip
   const int H0 = U.g.h0, W0 = U.g.w0;
@@ -594,6 +598,7 @@ int lmi_mask_logits(const float *proto, int batch, int nm, int mh, int mw, const
   GemmParams G;
   G.proto = proto; G.det = det; G.slot_map = slot_map; G.slot_base = slot_base; G.logits = reinterpret_cast<float *>(workspace);
   G.batch = batch; G.max_det = max_det; G.det_stride = det_stride; G.capacity = capacity_masks; G.g = g;
+  G.table = reinterpret_cast<int4 *>(reinterpret_cast<char *>(workspace) + align_up((size_t)capacity_masks * mh * mw * sizeof(float), 256));
   const int npx = (g.bottom - g.top) * mw;
   // LMI_MASK_LOGITS=mfma selects the dense MFMA tiles for every shape (a measurement knob: bench.py --mask-logits mfma)
   const char *mode = getenv("LMI_MASK_LOGITS");
@@ -603,6 +608,7 @@ int lmi_mask_logits(const float *proto, int batch, int nm, int mh, int mw, const
     hipLaunchKernelGGL(mask_logits_rows_kernel, dim3((tiles + 3) / 4, batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
     return lmi_check_launch("mask_logits_rows_kernel");
   }
+  hipLaunchKernelGGL(mask_slot_table_kernel, dim3((unsigned)((capacity_masks + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
   // dense MFMA tiles: 4 adjacent pixels per lane when rows are whole 16-byte vectors, else one pixel per lane
   const bool vec4 = (mw % 4) == 0 && lmi_is_aligned(proto, 16);
   const int ntiles = (npx + (vec4 ? 127 : 31)) / (vec4 ? 128 : 32);
@@ -674,7 +680,6 @@ int up_fill(const int32_t *slot_base, int batch, int h0, int w0, int px, void *o
 
 // the chunks that meet a box; ALU-bound, not store-bound: tall strips, so that a lane's horizontal taps serve many rows
 int up_boxes(UpCall &C, int out_dtype) {
-  hipLaunchKernelGGL(mask_slot_table_kernel, dim3((unsigned)((C.U.capacity + 255) / 256)), dim3(256), 0, C.s, C.U, const_cast<int4 *>(C.U.table));
   int rc = up_strip(C, 256, 1);
   if (rc) return rc;
   const size_t lds = (size_t)C.U.lds_rows * (C.g.right - C.g.left + 1) * sizeof(float);
