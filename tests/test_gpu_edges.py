@@ -215,3 +215,54 @@ def test_nms_halves_equal_the_one_call_form(ops, rotated):
         assert torch.equal(one[0][b, :c], two[0][b, :c]) and torch.equal(one[2][b, :c], two[2][b, :c])
     want, _ = OC.letterbox_u8(frames[1].cpu().numpy(), 160, 160)
     assert np.array_equal(lb[1].cpu().numpy(), want)
+
+
+def test_mask_upsample_two_pass_form_equals_single_pass_and_oracle(ops):
+    """Rows of whole 16-byte chunks take the zero-fill + box-pass form of lmi_mask_upsample: against the one-kernel
+    form (LMI_MASK_UPSAMPLE=single, read per call) bit for bit and against the oracle, on the layouts that stress
+    it: full-frame and out-of-frame boxes, empty boxes, > 256 chunk columns (fp32, 4K-wide rows), frames smaller
+    than the prototype window, and a buffer with more capacity than survivors (dead slots stay untouched)."""
+    import os
+    rng = np.random.default_rng(404)
+    nm = 32
+    cases = [  # (mh, mw, h0, w0, dtype)
+        (40, 40, 270, 480, torch.uint8), (40, 40, 270, 480, torch.float32), (80, 80, 1080, 1920, torch.uint8),
+        (40, 40, 135, 3840, torch.float32), (40, 52, 33, 48, torch.uint8), (80, 80, 2160, 3840, torch.uint8),
+        (160, 160, 64, 96, torch.uint8), (25, 40, 200, 16, torch.uint8), (20, 20, 17, 4, torch.float32),
+    ]
+    for ci, (mh, mw, h0, w0, dtype) in enumerate(cases):
+        B, max_det = 2, 8
+        proto = synth.proto(rng, B, nm, mh, mw)
+        det = np.zeros((B, max_det, 6 + nm), F32)
+        boxes = np.array([[0, 0, w0, h0], [-50, -30, w0 * 0.4, h0 * 0.5], [w0 * 0.3, h0 * 0.2, w0 + 40, h0 + 9],
+                          [w0 * 0.5, h0 * 0.5, w0 * 0.5, h0 * 0.9], [w0 + 5, 3, w0 + 50, 30], [w0 * 0.1, h0 * 0.6, w0 * 0.12, h0 * 0.61],
+                          [1.5, 2.5, 17.25, h0 - 0.5], [w0 * 0.7, h0 * 0.1, w0 * 0.95, h0 * 0.35]], F32)
+        n = [8, 5]
+        slot_map, slot_base = [], [0]
+        for b in range(B):
+            det[b, :n[b], :4] = boxes[rng.permutation(8)[:n[b]]]
+            det[b, :n[b], 6:] = rng.normal(0, 0.5, (n[b], nm))
+            slot_map += [b * max_det + i for i in range(n[b])]
+            slot_base.append(len(slot_map))
+        total, capacity = slot_base[-1], slot_base[-1] + 3
+        sm = np.full(B * max_det, -1, np.int32)
+        sm[:total] = slot_map
+        args = (dev(proto), dev(det), dev(sm), dev(np.array(slot_base, np.int32)), (h0, w0), capacity, dtype)
+        fill = 171 if dtype == torch.uint8 else 171.0
+        two = torch.full((capacity, h0, w0), fill, dtype=dtype, device="cuda")
+        one = torch.full((capacity, h0, w0), fill, dtype=dtype, device="cuda")
+        ops.process_mask(*args, out=two)
+        os.environ["LMI_MASK_UPSAMPLE"] = "single"
+        try:
+            ops.process_mask(*args, out=one)
+        finally:
+            del os.environ["LMI_MASK_UPSAMPLE"]
+        torch.cuda.synchronize()
+        assert torch.equal(two, one), f"case {ci}"
+        assert bool((two[total:] == fill).all()), f"case {ci}: dead slots were written"
+        got, k = two.cpu().numpy(), 0
+        for b in range(B):
+            ref = OM.process_mask_native(proto[b], det[b, :n[b], 6:], det[b, :n[b], :4], (h0, w0))
+            g = got[k:k + n[b]]
+            k += n[b]
+            assert (g != ref).sum() <= max(3, 0.001 * ref.sum()), f"case {ci} image {b}"
