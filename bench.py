@@ -11,7 +11,9 @@ no collective inside the timed region; RCCL only reduces the timings / counters 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (see the keys below); diagnostics go to stderr.
+The timed region replays one captured HIP graph per step (`--eager` launches every kernel from the host instead:
+seg640 1.273 vs 1.298 ms/step); the roofline kernel is then timed with HIP events in an eager pass of the same steps
+right after the timed region.  Prints ONE JSON line on rank 0 (see the keys below); diagnostics go to stderr.
 """
 from __future__ import annotations
 
@@ -162,8 +164,10 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=64, help="at most this many images of the workload are timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="stop the CPU sample after this much wall time")
     ap.add_argument("--seed", type=int, default=2)
-    ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per step in the timed region "
-                    "(the per-kernel roofline timing then comes from an eager, event-timed pass right after it)")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel of every step from the host instead of replaying "
+                    "one captured HIP graph per step (the default; the per-kernel roofline timing then comes from an eager, "
+                    "event-timed pass right after the timed region)")
+    ap.add_argument("--graph", action="store_true", help=argparse.SUPPRESS)   # the default since r01; kept for old command lines
     ap.add_argument("--no-fork", action="store_true", help="run the letterbox and the NMS chain on one stream (measurement)")
     ap.add_argument("--mask-logits", default="rows", choices=["rows", "mfma"],
                     help="coefficient x prototype product: row-sparse vector-ALU kernel (default) or dense fp32 MFMA tiles "
@@ -206,12 +210,19 @@ def main():
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     lb_evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     graph = None
-    if args.graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+    if not args.eager:
+        try:   # one step = one HIP graph (both streams of the fork are captured through the event dependencies)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = pipe.step(fork=fork)
+            graph.replay()
+            barrier()
+        except Exception as e:   # noqa: BLE001 -- a capture problem must not cost the measurement
+            log(f"[bench r{rank}] HIP graph capture failed ({type(e).__name__}: {e}); eager launches instead")
+            graph = None
+            torch.cuda.synchronize()
             out = pipe.step(fork=fork)
-        graph.replay()
-        barrier()
+            barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         if graph is not None:
@@ -297,7 +308,7 @@ def main():
             "config": {"workload": cfg["desc"], "name": args.workload, "per_gpu_batch": B, "conf": CONF, "iou": IOU,
                        "max_det": MAX_DET, "survivors_per_batch": n_surv, "nms_kept_per_batch": n_kept,
                        "per_rank": [{"images": int(r["images"]), "survivors": int(r["survivors"]), "kept_checksum": (int(r["chk_hi"]) << 31) | int(r["chk_lo"])} for r in reports],
-                       "mask_dtype": "uint8", "forward": "excluded", "launch": "hip graph replay" if args.graph else "eager", "streams": "letterbox forked beside NMS sort+suppress" if fork else "one", "mask_logits": args.mask_logits, "sharding": f"{world} x independent batches, no collective on the hot path"},
+                       "mask_dtype": "uint8", "forward": "excluded", "launch": "hip graph replay" if graph is not None else "eager", "streams": "letterbox forked beside NMS sort+suppress" if fork else "one", "mask_logits": args.mask_logits, "sharding": f"{world} x independent batches, no collective on the hot path"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(res), flush=True)
