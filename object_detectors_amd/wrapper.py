@@ -169,7 +169,7 @@ class Yolov8Core:
     # ---- postprocess (model.py:178-252) ----------------------------------------------------------
     @torch.inference_mode()
     def postprocess(self, preds, img, orig_imgs, conf: Union[float, dict], iou=0.45, agnostic=False, max_det=300, return_segments=True,
-                    _masks_on_device=False):
+                    _masks_on_device=False, _with_index=False):
         if isinstance(preds, (list, tuple)):
             predict_mask = preds[0].shape[1] != 4 + len(self.model.names)
         elif isinstance(preds, torch.Tensor):
@@ -218,7 +218,7 @@ class Yolov8Core:
         count_h = count.cpu().numpy()
         keep_h = keep.cpu().numpy().astype(bool)
         det_h = det[:, :, :6].cpu().numpy()
-        return self._assemble(det, det_h, count_h, keep_h, masks_by_image, orig_imgs, predict_mask, return_segments, _masks_on_device)
+        return self._assemble(det, det_h, count_h, keep_h, masks_by_image, orig_imgs, predict_mask, return_segments, _masks_on_device, _with_index)
 
     def _masks_one_image(self, ops, proto1, det1, keep1, shape):
         k = keep1[0].to(torch.int32)
@@ -232,9 +232,11 @@ class Yolov8Core:
         masks, _ = ops.process_mask(proto1, det1, slot_map, slot_base, shape, m, self.mask_dtype)
         return masks
 
-    def _assemble(self, det, det_h, count_h, keep_h, masks_by_image, orig_imgs, predict_mask, return_segments, masks_on_device=False):
+    def _assemble(self, det, det_h, count_h, keep_h, masks_by_image, orig_imgs, predict_mask, return_segments, masks_on_device=False,
+                  with_index=False):
         """Result dict exactly as model.py:214-252 builds it (images with no NMS survivor add no entry).
-        masks_on_device: leave the masks of numpy-input images on the GPU (predict reverts them there first)."""
+        masks_on_device: leave the masks of numpy-input images on the GPU (predict reverts them there first).
+        with_index: add the key 'image_index' (batch position of every entry), which the skip-empty rule loses."""
         results = collections.defaultdict(list)
         names = self.model.names
         for i in range(len(count_h)):
@@ -245,6 +247,8 @@ class Yolov8Core:
                 continue
             M = keep_h[i, :n]
             classes = np.array([names[int(c)] for c in det_h[i, :n, 5]])
+            if with_index:
+                results['image_index'].append(i)
             if predict_mask:
                 masks = masks_by_image[i]
                 if masks is None:
@@ -306,7 +310,8 @@ class Yolov8Core:
 
     # ---- additive: batched predict on raw frames -------------------------------------------------
     @torch.inference_mode()
-    def predict_batch(self, frames, configs, imgsz=(640, 640), swap_rb=False, iou=0.4, agnostic=False, max_det=300, return_segments=False):
+    def predict_batch(self, frames, configs, imgsz=(640, 640), swap_rb=False, iou=0.4, agnostic=False, max_det=300, return_segments=False,
+                      _with_index=False):
         """letterbox -> forward -> postprocess for a batch of raw frames; boxes and masks come back
         in each frame's own pixel space (scale_boxes / process_mask undo the letterbox), so no
         operator list is needed.  Returns (results dict as `postprocess`, time_info)."""
@@ -321,7 +326,7 @@ class Yolov8Core:
         time_info['proc'] = time.time() - t0
         t0 = time.time()
         origs = list(frames) if not isinstance(frames, list) else frames
-        results = self.postprocess(pred, im, origs, configs, iou, agnostic, max_det, return_segments)
+        results = self.postprocess(pred, im, origs, configs, iou, agnostic, max_det, return_segments, _with_index=_with_index)
         time_info['postproc'] = time.time() - t0
         return results, time_info
 

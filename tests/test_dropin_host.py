@@ -201,3 +201,26 @@ def test_contour_tracer_matches_oracle_on_host_arrays():
     got = PSG.masks2segments(torch.from_numpy(stack[:4].astype(np.float32)))
     for g, r in zip(got, SG.masks2segments(stack[:4])):
         assert np.array_equal(g, r)
+
+
+def test_folder_harness_csv_rows_and_batches(tmp_path):
+    """Host logic of object_detectors_amd/run_folder.py: the reference's csv rows (lmi_utils/label_utils/csv_utils.py:
+    125-129), last detection first (yolov8_lmi/run_model.py:108), truncating integer coordinates, sorted batches."""
+    import csv as _csv
+    from object_detectors_amd import run_folder as RF
+    rows = RF.result_rows("a.png", np.array([[1.9, 2.2, 30.7, 40.5], [5.0, 6.0, 7.0, 8.9]], np.float32), [0.91234, 0.5], ["cat", "dog"])
+    assert rows == [["a.png", "dog", "0.5000", "rect", "upper left", 5, 6, "angle", "0.00"],
+                    ["a.png", "dog", "0.5000", "rect", "lower right", 7, 8, "angle", "0.00"],
+                    ["a.png", "cat", "0.9123", "rect", "upper left", 1, 2, "angle", "0.00"],
+                    ["a.png", "cat", "0.9123", "rect", "lower right", 30, 40, "angle", "0.00"]]
+    segs = [np.array([[1.5, 2.5], [3.5, 4.5], [5.0, 6.0]], np.float32), np.zeros((0, 2), np.float32)]
+    rows = RF.result_rows("b.png", np.zeros((2, 4), np.float32), [0.7, 0.6], ["cat", "dog"], segs)
+    assert rows == [["b.png", "cat", "0.7000", "polygon", "x values", 1, 3, 5], ["b.png", "cat", "0.7000", "polygon", "y values", 2, 4, 6]]
+    RF.write_rows(rows, str(tmp_path / "p.csv"))
+    assert list(_csv.reader(open(tmp_path / "p.csv"), delimiter=";"))[1] == ["b.png", "cat", "0.7000", "polygon", "y values", "2", "4", "6"]
+    for name in ("b.png", "a.jpg", "c.txt", "d.BMP"):
+        (tmp_path / name).write_bytes(b"x")
+    (tmp_path / "sub").mkdir()
+    (tmp_path / "sub" / "e.jpeg").write_bytes(b"x")
+    got = RF.image_path_batches(2, str(tmp_path))
+    assert [[os.path.basename(p) for p in b] for b in got] == [["a.jpg", "b.png"], ["d.BMP", "e.jpeg"]]

@@ -194,3 +194,42 @@ def test_segments_from_device_masks_match_oracle():
             for g, r in zip(got, ref):
                 assert np.array_equal(g, r)
     assert sum(len(r) for r in ref) > 50
+
+
+def test_folder_harness_writes_the_reference_csv(models, tmp_path):
+    """run_folder (the file-in / file-out loop of yolov8_lmi/run_model.py:72-183): PNG files of mixed sizes and a grey
+    one -> preds.csv in the reference's format; rows equal what predict_batch gives frame by frame, in file order."""
+    import csv as _csv
+    from PIL import Image
+    from object_detectors_amd import run_folder
+    det, seg = models
+    rng = np.random.default_rng(5)
+    src = tmp_path / "imgs"
+    src.mkdir()
+    sizes = [(240, 320), (200, 200), (333, 251), (240, 320), (180, 320)]
+    for i, (h, w) in enumerate(sizes):
+        im = synth.frames_u8(rng, 1, h, w)[0]
+        Image.fromarray(im[:, :, 0] if i == 2 else im).save(src / f"f{i:02d}.png")
+    (src / "notes.txt").write_text("not an image")
+    for model, tag in ((det, "det"), (seg, "seg")):
+        out = tmp_path / tag
+        im, _ = model.letterbox([run_folder.load_rgb(str(src / f"f{i:02d}.png")) for i in range(5)], (256, 256))
+        y = model.forward(im)
+        conf = min(_conf_for((y[0] if isinstance(y, (list, tuple)) else y)[i:i + 1].cpu().numpy()) for i in range(5))
+        s = run_folder.run(model, str(src), str(out), (256, 256), conf, True, batch_size=2)
+        assert s["images"] == 5 and s["images_per_s"] > 0 and os.path.isfile(out / "summary.json")
+        rows = list(_csv.reader(open(out / "preds.csv"), delimiter=";"))
+        want = []
+        for p in sorted(os.listdir(src)):
+            if not p.endswith(".png"):
+                continue
+            res, _ = model.predict_batch([run_folder.load_rgb(str(src / p))], conf, imgsz=(256, 256), return_segments=True)
+            if len(res["boxes"]):
+                segs = res["segments"][0] if tag == "seg" else None
+                want += run_folder.result_rows(p, res["boxes"][0], res["scores"][0], res["classes"][0], segs)
+        assert s["detections"] > 0 and len(rows) == len(want) and len(rows) % 2 == 0
+        assert rows == [[str(v) for v in r] for r in want]
+        kinds = {r[3] for r in rows}
+        assert kinds == ({"polygon"} if tag == "seg" else {"rect"})
+        if tag == "det":
+            assert rows[0][4] == "upper left" and rows[1][4] == "lower right" and rows[0][7] == "angle" and rows[0][8] == "0.00"
