@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void mask_box_kernel(UpParams U) {
     }
     typedef float taps __attribute__((ext_vector_type(2), aligned(4)));
     // horizontal interpolation of one staged row at pixel k: depends on the source row only, so it is kept in
-    // registers across the consecutive output rows that share a source row pair (12 rows at 1080p from 160x160)
+    // registers across the consecutive output rows that share a source row pair (6-7 rows at 1080p from 160x160)
     auto hrow = [&](int iy, int k) -> float {
       const taps a = *reinterpret_cast<const taps *>(reinterpret_cast<const char *>(L + (iy - ly_first) * ls) + oa[k]);
       const f2 p = f2{a.x, a.y} * wx[k];   // packed fp32 multiply, each half rounded as the scalar form
