@@ -269,47 +269,69 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
     if (lane < m) cb = in_lds ? lbox[base + lane] : sbox[base + lane];
     const float carea = (cb.z - cb.x) * (cb.w - cb.y);
 
-    // A: chunk vs kept boxes, kept index strided over the 16 waves
-    // four kept boxes per iteration, no short-circuit: the 20 LDS broadcasts are issued together instead of one
-    // dependent round trip per kept box
+    // A: chunk vs kept boxes, kept index strided over the 16 waves, four kept boxes per iteration so that the LDS
+    // broadcasts are issued together.  Most kept boxes cannot meet any candidate of the chunk (another class --
+    // the class offset moves it 7680 px away -- or another place): a kept box whose x-extent meets no lane's
+    // (xx2 > xx1 is necessary for inter > 0, exactly) is dropped by one wave-uniform branch before the y-extents,
+    // areas and the division are touched.
     bool hit = false;
     constexpr int NW = kSortThreads / 64;
     int k = wave;
     for (; k + 3 * NW < K; k += 4 * NW) {
-      const bool h0 = iou_gt(kx1[k], ky1[k], kx2[k], ky2[k], karea[k], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
-      const bool h1 = iou_gt(kx1[k + NW], ky1[k + NW], kx2[k + NW], ky2[k + NW], karea[k + NW], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
-      const bool h2 = iou_gt(kx1[k + 2 * NW], ky1[k + 2 * NW], kx2[k + 2 * NW], ky2[k + 2 * NW], karea[k + 2 * NW], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
-      const bool h3 = iou_gt(kx1[k + 3 * NW], ky1[k + 3 * NW], kx2[k + 3 * NW], ky2[k + 3 * NW], karea[k + 3 * NW], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
+      const float a0 = kx1[k], a1 = kx1[k + NW], a2 = kx1[k + 2 * NW], a3 = kx1[k + 3 * NW];
+      const float e0 = kx2[k], e1 = kx2[k + NW], e2 = kx2[k + 2 * NW], e3 = kx2[k + 3 * NW];
+      const bool o0 = fminf(e0, cb.z) > fmaxf(a0, cb.x), o1 = fminf(e1, cb.z) > fmaxf(a1, cb.x);
+      const bool o2 = fminf(e2, cb.z) > fmaxf(a2, cb.x), o3 = fminf(e3, cb.z) > fmaxf(a3, cb.x);
+      if (__ballot(o0 | o1 | o2 | o3) == 0ull) continue;
+      const bool h0 = iou_gt(a0, ky1[k], e0, ky2[k], karea[k], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
+      const bool h1 = iou_gt(a1, ky1[k + NW], e1, ky2[k + NW], karea[k + NW], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
+      const bool h2 = iou_gt(a2, ky1[k + 2 * NW], e2, ky2[k + 2 * NW], karea[k + 2 * NW], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
+      const bool h3 = iou_gt(a3, ky1[k + 3 * NW], e3, ky2[k + 3 * NW], karea[k + 3 * NW], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
       hit = hit | h0 | h1 | h2 | h3;
     }
-    for (; k < K; k += NW)
-      hit = hit | iou_gt(kx1[k], ky1[k], kx2[k], ky2[k], karea[k], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
+    for (; k < K; k += NW) {
+      const float a0 = kx1[k], e0 = kx2[k];
+      if (__ballot(fminf(e0, cb.z) > fmaxf(a0, cb.x)) == 0ull) continue;
+      hit = hit | iou_gt(a0, ky1[k], e0, ky2[k], karea[k], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
+    }
     if (hit && lane < m) supp[lane] = 1;
 
-    // B: pair masks inside the chunk: row j = lanes i > j that j would suppress
+    // B: pair masks inside the chunk, by column: pairmask[j] = lanes i < j whose box would suppress j's (same
+    // x-extent shortcut: the boxes of one chunk are mostly of different classes)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int j = wave * 4 + q;  // wave-uniform
-      const float jx1 = __shfl(cb.x, j), jy1 = __shfl(cb.y, j), jx2 = __shfl(cb.z, j), jy2 = __shfl(cb.w, j);
-      const float jarea = __shfl(carea, j);
-      const bool p = (lane > j) && (lane < m) && (j < m) && iou_gt(jx1, jy1, jx2, jy2, jarea, cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
-      const uint64_t mask = __ballot(p);
+      const int j = __builtin_amdgcn_readfirstlane(wave) * 4 + q;  // wave-uniform: the box of lane j comes by readlane
+      const float bx1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb.x), j));
+      const float bx2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb.z), j));
+      uint64_t mask = 0ull;
+      if (__ballot((lane < j) && fminf(cb.z, bx2) > fmaxf(cb.x, bx1)) != 0ull) {
+        const float by1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb.y), j));
+        const float by2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb.w), j));
+        const float barea = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(carea), j));
+        const bool p = (lane < j) && (j < m) && iou_gt(cb.x, cb.y, cb.z, cb.w, carea, bx1, by1, bx2, by2, barea, S.iou_thr);
+        mask = __ballot(p);
+      }
       if (lane == 0) pairmask[j] = mask;
     }
     __syncthreads();
 
     if (wave == 0) {
-      uint64_t alive = __ballot(lane < m && supp[lane] == 0);
-      const uint64_t pm = pairmask[lane];
-      uint64_t keepm = 0;
-      int Kl = K;
-      while (alive != 0 && Kl < S.max_det) {
-        const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(alive));
-        keepm |= 1ull << j;
-        ++Kl;
-        alive &= ~readlane_u64(pm, j);
-        alive &= ~(1ull << j);
+      // Greedy suppression inside the chunk as a fixpoint: S = candidates kept so far; lane j stays iff it is alive
+      // and no kept i < j suppresses it.  After t rounds the first t lanes are final (by induction on j), so the
+      // loop ends within 64 rounds and a round that changes nothing has reached the greedy answer -- in practice
+      // after the length of the longest suppression chain, 2-5 rounds, instead of one serial step per kept box.
+      const uint64_t alive = __ballot(lane < m && supp[lane] == 0);
+      const uint64_t col = pairmask[lane];
+      uint64_t keep_set = alive;
+      for (int round = 0; round < 65; ++round) {   // 64 rounds settle every lane; the bound is belt and braces
+        const uint64_t next = alive & ~__ballot((col & keep_set) != 0ull);
+        if (next == keep_set) break;
+        keep_set = next;
       }
+      // at most max_det rows in all: the first (max_det - K) kept lanes of this chunk
+      const int rank = __builtin_popcountll(keep_set & ((1ull << lane) - 1ull));
+      const uint64_t keepm = __ballot(((keep_set >> lane) & 1ull) && K + rank < S.max_det);
+      const int Kl = K + __builtin_popcountll(keepm);
       if ((keepm >> lane) & 1ull) {
         const int idx = K + __builtin_popcountll(keepm & ((1ull << lane) - 1ull));
         kx1[idx] = cb.x; ky1[idx] = cb.y; kx2[idx] = cb.z; ky2[idx] = cb.w;
