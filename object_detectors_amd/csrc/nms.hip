@@ -168,6 +168,46 @@ __device__ __forceinline__ void bitonic_desc(KeyPtr a, int P2) {
   }
 }
 
+// The same network for keys in LDS with far fewer workgroup barriers: strides shorter than a wave's segment of the
+// array (>= 128 keys) touch that segment only, so the wave that owns it runs all of them back to back -- LDS
+// operations of one wave complete in order, a wavefront-scope fence keeps the compiler from moving them -- and the
+// workgroup meets only around the strides that cross segments: 15 barriers instead of 66 for 2048 keys.
+__device__ __forceinline__ void bitonic_desc_lds(uint64_t *a, int P2) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = kSortThreads / 64;
+  const int seg = P2 < 128 ? P2 : max(128, P2 / NW);
+  const int nseg = P2 / seg;
+  const int base = wave * seg;
+  for (int k = 2; k <= P2; k <<= 1) {
+    int j = k >> 1;
+    for (; j >= seg; j >>= 1) {   // strides across segments: every lane of the workgroup, then a barrier
+      for (int t = tid; t < (P2 >> 1); t += kSortThreads) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int p = i | j;
+        const uint64_t x = a[i], y = a[p];
+        const bool desc = (i & k) == 0;
+        if (desc ? (x < y) : (x > y)) { a[i] = y; a[p] = x; }
+      }
+      __syncthreads();
+    }
+    if (wave < nseg) {
+      for (; j > 0; j >>= 1) {    // strides inside this wave's segment
+        for (int t = lane; t < (seg >> 1); t += 64) {
+          const int i = base + (((t & ~(j - 1)) << 1) | (t & (j - 1)));
+          const int p = i | j;
+          const uint64_t x = a[i], y = a[p];
+          const bool desc = (i & k) == 0;
+          if (desc ? (x < y) : (x > y)) { a[i] = y; a[p] = x; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+    if (k >= seg) __syncthreads();   // the next stage starts with a stride across segments (or the sort is done)
+  }
+}
+
 __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay2, float aarea, float bx1, float by1,
                                        float bx2, float by2, float barea, float thr) {
   const float xx1 = fmaxf(ax1, bx1), yy1 = fmaxf(ay1, by1);
@@ -239,7 +279,7 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
   if (in_lds) {
     for (int i = tid; i < P2; i += kSortThreads) lkeys[i] = (i < n) ? gkeys[i] : 0ull;
     __syncthreads();
-    bitonic_desc(lkeys, P2);
+    bitonic_desc_lds(lkeys, P2);
   } else {
     for (int i = n + tid; i < P2; i += kSortThreads) gkeys[i] = 0ull;
     __syncthreads();
@@ -418,7 +458,7 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_rotated(SortNmsParams S
   if (in_lds) {
     for (int i = tid; i < P2; i += kSortThreads) lkeys[i] = (i < n) ? gkeys[i] : 0ull;
     __syncthreads();
-    bitonic_desc(lkeys, P2);
+    bitonic_desc_lds(lkeys, P2);
   } else {
     for (int i = n + tid; i < P2; i += kSortThreads) gkeys[i] = 0ull;
     __syncthreads();
