@@ -11,10 +11,13 @@
 //                     anchor, strict fp32 `> conf`, wave-ballot compaction of (score, anchor) keys.
 //  nms_sort_suppress  one 1024-lane workgroup per image (latency-bound, LDS-resident): bitonic
 //                     sort of the 64-bit keys (score desc, anchor asc = torchvision's stable
-//                     order), then greedy NMS in 64-candidate chunks: every wave tests the chunk
-//                     against the kept boxes held in LDS, pair masks inside the chunk come from
-//                     wave ballots, one wave resolves the chunk serially with readlane.  Stops
-//                     after max_det keeps (later candidates cannot change earlier keeps).
+//                     order), then the greedy pass.  Per-class NMS with <= 128 classes and <= 2048
+//                     candidates: decomposed by class (class_parallel_nms: one lane per candidate,
+//                     bit rows of suppressing predecessors, fixpoint rounds, no per-chunk barriers).
+//                     Otherwise (agnostic, many classes, a class of > 256 candidates, ...): 64-candidate
+//                     chunks, every wave tests the chunk against the kept boxes held in LDS, pair masks
+//                     inside the chunk come from wave ballots, the chunk's greedy answer is a fixpoint
+//                     in one wave.  Both stop at max_det keeps.
 //  finalize_boxes_kernel  one workgroup per image: scale/clip boxes in place, per-class threshold, ranks.
 //  finalize_slots_kernel  one workgroup per image: prefix of the keep counts -> dense global mask slots and their inverse map.
 #include <cmath>
@@ -225,6 +228,180 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int srclane) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Class-parallel suppression.  With per-class NMS the class offset (cls * max_wh) moves the boxes of different
+// classes so far apart that they cannot intersect, PROVIDED the x-extent of all candidates together is below
+// max_wh (checked per image; the fp32 rounding of the offset coordinates is below 0.1 px for <= 128 classes).
+// torchvision's greedy pass over the score-ordered list then decomposes into independent greedy passes per class,
+// each over that class's candidates in the same order and on the same offset coordinates -- identical keeps.
+// So instead of walking the list in 64-candidate chunks with two workgroup barriers each:
+//   1. the candidates are grouped by class (LDS counting pass; the order inside a class does not matter);
+//   2. one lane per candidate j tests j against the members of its class that precede it in the list and keeps
+//      the outcomes as a bit row (classes of <= 256 candidates: up to four 64-bit words per candidate);
+//   3. the greedy answer of every class is the fixpoint of  keep_j = no kept predecessor suppresses j,  reached by
+//      rounds over all candidates at once (after t rounds the first t members of every class are final, so at most
+//      64 rounds; in practice the length of the longest suppression chain);
+//   4. the kept flags are compacted in list order.
+// Falls back (returns false, nothing written) when: agnostic, > kCpMaxClasses classes, the extent check fails, a
+// class holds more than 256 candidates, or the LDS scratch -- the unused upper part of the box buffer -- is too small.
+constexpr int kCpMaxClasses = 128;
+constexpr int kCpWords = 4;   // 64-bit words of a class's member set: classes of up to 256 candidates
+
+struct CpScratch {
+  int *ccount, *cstart;     // [ncp] candidates per class, first slot of the class in grp
+  uint64_t *keep_a, *keep_b;  // [ncp][kCpWords] kept members of every class (bit = slot inside the class), two generations
+  int *misc;                // [0] largest class, [1..17] wave totals of the compaction
+  unsigned short *lcls;     // [P2] class of the sorted candidate
+  unsigned short *grp;      // [P2] list positions grouped by class
+  unsigned char *slotof;    // [P2] slot of the sorted candidate inside its class
+};
+
+__device__ __forceinline__ size_t cp_bytes(int P2, int ncp) { return (size_t)ncp * (16 * kCpWords + 8) + 32 * 4 + (size_t)P2 * 5 + 64; }
+
+__device__ __forceinline__ CpScratch cp_carve(unsigned char *base, int P2, int ncp) {
+  CpScratch C;
+  unsigned char *q = base;                                    // 16-byte aligned (inside the float4 box buffer)
+  C.keep_a = reinterpret_cast<uint64_t *>(q); q += (size_t)ncp * 8 * kCpWords;
+  C.keep_b = reinterpret_cast<uint64_t *>(q); q += (size_t)ncp * 8 * kCpWords;
+  C.ccount = reinterpret_cast<int *>(q); q += (size_t)ncp * 4;
+  C.cstart = reinterpret_cast<int *>(q); q += (size_t)ncp * 4;
+  C.misc = reinterpret_cast<int *>(q); q += 32 * 4;
+  C.lcls = reinterpret_cast<unsigned short *>(q); q += (size_t)P2 * 2;
+  C.grp = reinterpret_cast<unsigned short *>(q); q += (size_t)P2 * 2;
+  C.slotof = q;
+  return C;
+}
+
+// All lanes of the workgroup call this (uniform control flow).  lbox: offset boxes of the n_eff sorted candidates
+// (n_eff <= 2 * kSortThreads); C.lcls filled by the caller.  On success kpos[0..K) holds the kept list positions
+// in order and *sK = K.
+__device__ bool class_parallel_nms(const CpScratch &C, const float4 *lbox, int n_eff, int P2, int nc, int ncp, int max_det,
+                                   float thr, int *kpos, int *sK) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = kSortThreads / 64;
+
+  // 1. group by class
+  if (tid < ncp) C.ccount[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < n_eff; i += kSortThreads) {
+    const int r = atomicAdd(&C.ccount[C.lcls[i]], 1);
+    C.slotof[i] = (unsigned char)min(r, 255);
+  }
+  __syncthreads();
+  if (wave == 0) {   // class starts (ncp <= 128: two classes per lane) and the largest class
+    const int a = 2 * lane < ncp ? C.ccount[2 * lane] : 0, b2 = 2 * lane + 1 < ncp ? C.ccount[2 * lane + 1] : 0;
+    int incl = a + b2, big = max(a, b2);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int u = __shfl_up(incl, d), g = __shfl_xor(big, d);
+      if (lane >= d) incl += u;
+      big = max(big, g);
+    }
+    if (2 * lane < ncp) C.cstart[2 * lane] = incl - a - b2;
+    if (2 * lane + 1 < ncp) C.cstart[2 * lane + 1] = incl - b2;
+    if (lane == 0) C.misc[0] = big;
+  }
+  __syncthreads();
+  if (C.misc[0] > 64 * kCpWords) return false;   // uniform
+  const int W = (C.misc[0] + 63) >> 6;             // words in use for this image
+  for (int i = tid; i < n_eff; i += kSortThreads) C.grp[C.cstart[C.lcls[i]] + C.slotof[i]] = (unsigned short)i;
+  for (int e = tid; e < ncp * kCpWords; e += kSortThreads) {
+    const int m = C.ccount[e / kCpWords] - 64 * (e % kCpWords);   // members in this word
+    C.keep_a[e] = m >= 64 ? ~0ull : (m > 0 ? ((1ull << m) - 1ull) : 0ull);   // generation 0: everybody
+    C.keep_b[e] = 0ull;
+  }
+  __syncthreads();
+
+  // 2. one lane per candidate, in class-grouped order (the lanes of a wave walk classes of similar length and read
+  //    the same members: LDS broadcasts): bit r = member r of my class precedes me in the list and would suppress me
+  uint64_t bits[2][kCpWords] = {};
+  int myc[2] = {0, 0}, myslot[2] = {0, 0};
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int g = tid + kSortThreads * u;
+    if (g >= n_eff) break;
+    const int j = C.grp[g];
+    const int c = C.lcls[j], sc = C.cstart[c], mc = C.ccount[c];
+    myc[u] = c; myslot[u] = g - sc;
+    const float4 cb = lbox[j];
+    const float carea = (cb.z - cb.x) * (cb.w - cb.y);
+#pragma unroll
+    for (int w = 0; w < kCpWords; ++w) {
+      if (w >= W) break;   // uniform
+      uint64_t bset = 0ull;
+      const int r1 = min(64, mc - 64 * w);
+      for (int r = 0; r < r1; ++r) {
+        const int pr = C.grp[sc + 64 * w + r];
+        if (pr < j) {
+          const float4 kb = lbox[pr];
+          if (iou_gt(kb.x, kb.y, kb.z, kb.w, (kb.z - kb.x) * (kb.w - kb.y), cb.x, cb.y, cb.z, cb.w, carea, thr)) bset |= 1ull << r;
+        }
+      }
+      bits[u][w] = bset;
+    }
+  }
+
+  // 3. fixpoint rounds over all classes at once
+  uint64_t *cur = C.keep_a, *nxt = C.keep_b;
+  for (int round = 0; round < 64 * kCpWords + 1; ++round) {   // a class of m members settles within m rounds
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int g = tid + kSortThreads * u;
+      if (g < n_eff) {
+        uint64_t suppressed = 0ull;
+#pragma unroll
+        for (int w = 0; w < kCpWords; ++w)
+          if (w < W) suppressed |= bits[u][w] & cur[myc[u] * kCpWords + w];
+        if (suppressed == 0ull)
+          atomicOr(reinterpret_cast<unsigned long long *>(&nxt[myc[u] * kCpWords + (myslot[u] >> 6)]), 1ull << (myslot[u] & 63));
+      }
+    }
+    __syncthreads();
+    int changed = 0;
+    for (int e = tid; e < ncp * kCpWords; e += kSortThreads) {
+      changed |= nxt[e] != cur[e];
+      cur[e] = 0ull;   // becomes the next round's accumulator
+    }
+    changed = __syncthreads_or(changed);
+    uint64_t *t = cur; cur = nxt; nxt = t;
+    if (!changed) break;
+  }
+  // cur = the kept members of every class
+
+  // 4. compaction in list order: thread t owns positions [per * t, per * t + per)
+  const int per = (P2 + kSortThreads - 1) / kSortThreads;
+  int mine = 0;
+  for (int u = 0; u < per; ++u) {
+    const int i = per * tid + u;
+    if (i < n_eff) mine += (int)((cur[C.lcls[i] * kCpWords + (C.slotof[i] >> 6)] >> (C.slotof[i] & 63)) & 1ull);
+  }
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int u = __shfl_up(incl, d);
+    if (lane >= d) incl += u;
+  }
+  if (lane == 63) C.misc[1 + wave] = incl;
+  __syncthreads();
+  int before = 0, total = 0;
+  for (int w = 0; w < NW; ++w) {
+    const int v = C.misc[1 + w];
+    if (w < wave) before += v;
+    total += v;
+  }
+  int idx = before + incl - mine;
+  for (int u = 0; u < per; ++u) {
+    const int i = per * tid + u;
+    if (i < n_eff && ((cur[C.lcls[i] * kCpWords + (C.slotof[i] >> 6)] >> (C.slotof[i] & 63)) & 1ull)) {
+      if (idx < max_det) kpos[idx] = i;
+      ++idx;
+    }
+  }
+  if (tid == 0) *sK = min(total, max_det);
+  __syncthreads();
+  return true;
+}
+
 struct SortNmsParams {
   const float *pred;
   int nc, nm, A;
@@ -288,22 +465,65 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
   const int n_eff = min(n, S.max_nms);
 
   // ---- decode the sorted candidates' (class-offset) boxes ------------------------------------------
+  // class-parallel suppression (see class_parallel_nms) needs: per-class NMS, few classes, the candidates in LDS
+  // and room for its scratch in the part of the LDS box buffer that this image does not use
+  const int ncp = (S.nc + 1) & ~1;
+  const bool cp_try = in_lds && !S.agnostic && S.nc <= kCpMaxClasses && P2 <= 2 * kSortThreads &&
+                      (size_t)(S.lds_keys - P2) * sizeof(float4) >= cp_bytes(P2, ncp);
+  CpScratch CP{};
+  if (cp_try) CP = cp_carve(reinterpret_cast<unsigned char *>(lbox + P2), P2, ncp);
+  float lo_x = INFINITY, hi_x = -INFINITY;   // x-extent of the candidates before the class offset
   for (int i = tid; i < n_eff; i += kSortThreads) {
     const uint64_t key = in_lds ? lkeys[i] : gkeys[i];
     const uint32_t anchor = ~(uint32_t)key;
     const float cx = pb[anchor], cy = pb[(size_t)A + anchor], w = pb[(size_t)2 * A + anchor], h = pb[(size_t)3 * A + anchor];
     const float hw = w / 2.0f, hh = h / 2.0f;
-    const float c = S.agnostic ? 0.0f : (float)S.cls_of[(size_t)b * A + anchor] * S.max_wh;
+    const int cls = S.agnostic ? 0 : S.cls_of[(size_t)b * A + anchor];
+    const float c = S.agnostic ? 0.0f : (float)cls * S.max_wh;
     const float4 bx = make_float4((cx - hw) + c, (cy - hh) + c, (cx + hw) + c, (cy + hh) + c);
     if (in_lds) lbox[i] = bx; else sbox[i] = bx;
+    if (cp_try) {
+      CP.lcls[i] = (unsigned short)cls;
+      // NaN coordinates must fail the extent test below: fminf / fmaxf would drop them
+      lo_x = (cx - hw) < lo_x ? (cx - hw) : ((cx - hw) >= lo_x ? lo_x : NAN);
+      hi_x = (cx + hw) > hi_x ? (cx + hw) : ((cx + hw) <= hi_x ? hi_x : NAN);
+    }
+  }
+  bool cp_go = false;
+  if (cp_try) {   // uniform
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      const float l2 = __shfl_xor(lo_x, d), h2 = __shfl_xor(hi_x, d);
+      lo_x = (l2 < lo_x) ? l2 : ((l2 >= lo_x) ? lo_x : NAN);
+      hi_x = (h2 > hi_x) ? h2 : ((h2 <= hi_x) ? hi_x : NAN);
+    }
+    float *part = reinterpret_cast<float *>(supp);   // 64 ints, zeroed again below
+    if (lane == 0) { part[wave] = lo_x; part[16 + wave] = hi_x; }
+    __syncthreads();
+    float lo = part[0], hi = part[16];
+    for (int w = 1; w < kSortThreads / 64; ++w) {
+      const float l2 = part[w], h2 = part[16 + w];
+      lo = (l2 < lo) ? l2 : ((l2 >= lo) ? lo : NAN);
+      hi = (h2 > hi) ? h2 : ((h2 <= hi) ? hi : NAN);
+    }
+    // boxes of different classes cannot intersect when every candidate lies inside one max_wh-wide band
+    cp_go = (hi - lo) <= S.max_wh - 1.0f;   // false for NaN
+    __syncthreads();
   }
   if (tid < 64) supp[tid] = 0;
   if (tid == 0) *sK = 0;
   __syncthreads();
 
-  // ---- greedy NMS in chunks of 64 sorted candidates ---------------------------------------------
   int K = 0;
-  for (int base = 0; base < n_eff && K < S.max_det; base += 64) {
+  bool done = false;
+  if (cp_go) {
+    done = class_parallel_nms(CP, lbox, n_eff, P2, S.nc, ncp, S.max_det, S.iou_thr, kpos, sK);
+    if (done) K = *sK;
+  }
+
+  // ---- greedy NMS in chunks of 64 sorted candidates (agnostic NMS, many classes, a very large class, boxes
+  //      wider than the class offset, or more candidates than the LDS buffers hold) ------------------------------
+  for (int base = 0; !done && base < n_eff && K < S.max_det; base += 64) {
     const int m = min(64, n_eff - base);
     float4 cb = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lane < m) cb = in_lds ? lbox[base + lane] : sbox[base + lane];
@@ -820,14 +1040,14 @@ static int nms_suppress(const NmsCall &C, const float *pred, int batch, int nc, 
     const size_t head = (size_t)S.lds_keys * 8 + 4 * (size_t)((max_det + 1) & ~1) + 4 * 17 + 16;
     S.lbox_off = (int)((head + 15) & ~(size_t)15);
     const size_t lds_rot = (size_t)S.lbox_off + (size_t)S.lds_keys * (16 + 8);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_rotated), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_rotated), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rot);
     hipLaunchKernelGGL(nms_sort_rotated, dim3(batch), dim3(kSortThreads), lds_rot, C.s, S);
     return lmi_check_launch("nms_sort_rotated");
   }
   const size_t lds_small = (size_t)S.lds_keys * 8 + 4 * 6 * (size_t)((max_det + 1) & ~1) + 64 * 8 + 64 * 4 + 16;
   S.lbox_off = (int)((lds_small + 15) & ~(size_t)15);
   const size_t lds = (size_t)S.lbox_off + (size_t)S.lds_keys * 16;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_suppress), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_suppress), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(nms_sort_suppress, dim3(batch), dim3(kSortThreads), lds, C.s, S);
   return lmi_check_launch("nms_sort_suppress");
 }

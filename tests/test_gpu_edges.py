@@ -266,3 +266,52 @@ def test_mask_upsample_two_pass_form_equals_single_pass_and_oracle(ops):
             g = got[k:k + n[b]]
             k += n[b]
             assert (g != ref).sum() <= max(3, 0.001 * ref.sum()), f"case {ci} image {b}"
+
+
+def test_nms_class_parallel_path_boundaries(ops):
+    """The per-class decomposition of the greedy pass (class_parallel_nms in nms.hip) and its fallbacks, against the
+    oracle's plain greedy NMS on the class-offset boxes: classes of exactly 64 / 65 / 256 / 257 candidates (one,
+    two, four words per bit row, fallback), 128 and 129 classes, boxes spread wider than the class offset (the
+    decomposition is not valid there: chunked path), max_det cutting the kept list, heavy overlap inside a class."""
+    rng = np.random.default_rng(909)
+
+    def head(class_sizes, A, spread=600.0, nc=None, big=None):
+        nc = nc or len(class_sizes)
+        p = np.zeros((1, 4 + nc, A), F32)
+        p[0, 4:] = 0.01
+        n = sum(class_sizes)
+        idx = rng.permutation(A)[:n]
+        centres = rng.uniform(40, spread, (max(1, n // 6), 2))
+        k = 0
+        for c, m in enumerate(class_sizes):
+            for _ in range(m):
+                a = idx[k]; k += 1
+                ctr = centres[rng.integers(0, len(centres))] + rng.normal(0, 3.0, 2)
+                p[0, 0, a], p[0, 1, a] = ctr
+                p[0, 2, a], p[0, 3, a] = rng.uniform(20, 60, 2)
+                p[0, 4 + c, a] = rng.uniform(0.3, 0.95)
+        if big is not None:   # one candidate far outside the max_wh band
+            p[0, 0, idx[0]] = big
+        return p
+
+    cases = [
+        dict(sizes=[64, 3, 10]), dict(sizes=[65, 64, 1]), dict(sizes=[256, 20]), dict(sizes=[257, 20]),
+        dict(sizes=[128, 129, 130, 1, 0, 7]), dict(sizes=[5] * 128), dict(sizes=[5] * 129),
+        dict(sizes=[40, 30, 20], big=9000.0), dict(sizes=[40, 30, 20], spread=7700.0),
+        dict(sizes=[200, 100, 50], max_det=7), dict(sizes=[300, 300, 300, 300], max_det=300),
+        dict(sizes=[63, 1, 64, 2, 65]), dict(sizes=[1]), dict(sizes=[2, 0, 0, 1]),
+    ]
+    for ci, cs in enumerate(cases):
+        sizes = cs["sizes"]
+        A = 2100
+        p = head(sizes, A, spread=cs.get("spread", 600.0), big=cs.get("big"))
+        nc = len(sizes)
+        for iou in (0.45, 0.2):
+            md = cs.get("max_det", 300)
+            det, count, anchor = ops.nms_v8(dev(p), 0.25, iou, max_det=md, nc=nc)
+            torch.cuda.synchronize()
+            (rd, ra), = ON.non_max_suppression(p, 0.25, iou, max_det=md, nc=nc)
+            n = int(count[0])
+            tag = f"case {ci} sizes={sizes[:6]} iou={iou}"
+            assert anchor[0, :n].cpu().numpy().tolist() == ra.tolist(), tag
+            assert n == 0 or np.abs(det[0, :n].cpu().numpy() - rd).max() <= 1e-3, tag
