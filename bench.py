@@ -186,7 +186,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("LMI_BENCH_FORCE_DIST"):   # the variable: a one-rank rehearsal of the multi-GPU path on a one-GPU box
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -213,7 +213,8 @@ def main():
     if not args.eager:
         try:   # one step = one HIP graph (both streams of the fork are captured through the event dependencies)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: RCCL's watchdog thread may touch the device while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = pipe.step(fork=fork)
             graph.replay()
             barrier()
