@@ -15,6 +15,13 @@ from object_detectors_amd import synth
 F32 = np.float32
 
 
+def sweep_seeds(first):
+    """The committed seed of a differential sweep, plus LMI_FUZZ_EXTRA more (a one-off soak on the GPU box:
+    `LMI_FUZZ_EXTRA=40 python -m pytest tests/test_gpu_edges.py -m gpu -k "random or boundaries"`)."""
+    import os
+    return [first] + [10_000 + first + k for k in range(int(os.environ.get("LMI_FUZZ_EXTRA", "0")))]
+
+
 @pytest.fixture(scope="module")
 def ops():
     assert torch.cuda.is_available(), "these tests need the GPU"
@@ -104,10 +111,11 @@ def test_boxes_on_the_frame_border_and_outside(ops):
     assert got[3].sum() == 0            # zero-width box
 
 
-def test_letterbox_random_geometries_one_ragged_batch(ops):
+@pytest.mark.parametrize("seed", sweep_seeds(2024))
+def test_letterbox_random_geometries_one_ragged_batch(ops, seed):
     """Differential sweep: 48 random frame sizes (tiny to wide, up- and down-scales, odd strides of the scale factor) in
     ragged batches against the oracle, bit for bit, over the option combinations."""
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(seed)
     sizes = [(int(rng.integers(1, 300)), int(rng.integers(1, 400))) for _ in range(40)]
     sizes += [(719, 1279), (1081, 1921), (97, 1003), (1003, 97), (640, 640), (641, 639), (320, 320), (159, 161)]
     frames = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
@@ -124,10 +132,11 @@ def test_letterbox_random_geometries_one_ragged_batch(ops):
             assert bad.shape[0] == 0, f"frame {sizes[b]} -> {(dh, dw)} stretch={stretch}: {bad.shape[0]} mismatches, first {bad[:4].tolist()}"
 
 
-def test_nms_random_configurations_with_score_ties(ops):
+@pytest.mark.parametrize("seed", sweep_seeds(77))
+def test_nms_random_configurations_with_score_ties(ops, seed):
     """Differential sweep over head shapes and NMS settings; scores quantised to 1/128 so that many candidates tie
     and the order rule (equal scores keep anchor order, torch.sort stable) decides the kept set."""
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(seed)
     for trial in range(24):
         nc = int(rng.choice([1, 2, 7, 80]))
         nm = int(rng.choice([0, 0, 32, 5]))
@@ -150,9 +159,10 @@ def test_nms_random_configurations_with_score_ties(ops):
             assert n == 0 or np.abs(det[b, :n].cpu().numpy() - rd).max() <= 1e-3, tag
 
 
-def test_process_mask_random_shapes(ops):
+@pytest.mark.parametrize("seed", sweep_seeds(303))
+def test_process_mask_random_shapes(ops, seed):
     """Differential sweep over prototype sizes (odd widths and non-square included), frame sizes and box layouts."""
-    rng = np.random.default_rng(303)
+    rng = np.random.default_rng(seed)
     nm = 32
     for trial in range(14):
         mh, mw = int(rng.choice([20, 25, 40, 41, 80])), int(rng.choice([20, 25, 40, 52, 80]))
@@ -268,12 +278,13 @@ def test_mask_upsample_two_pass_form_equals_single_pass_and_oracle(ops):
             assert (g != ref).sum() <= max(3, 0.001 * ref.sum()), f"case {ci} image {b}"
 
 
-def test_nms_class_parallel_path_boundaries(ops):
+@pytest.mark.parametrize("seed", sweep_seeds(909))
+def test_nms_class_parallel_path_boundaries(ops, seed):
     """The per-class decomposition of the greedy pass (class_parallel_nms in nms.hip) and its fallbacks, against the
     oracle's plain greedy NMS on the class-offset boxes: classes of exactly 64 / 65 / 256 / 257 candidates (one,
     two, four words per bit row, fallback), 128 and 129 classes, boxes spread wider than the class offset (the
     decomposition is not valid there: chunked path), max_det cutting the kept list, heavy overlap inside a class."""
-    rng = np.random.default_rng(909)
+    rng = np.random.default_rng(seed)
 
     def head(class_sizes, A, spread=600.0, nc=None, big=None):
         nc = nc or len(class_sizes)

@@ -35,9 +35,14 @@ def test_golden_reference_outputs(ops):
         assert oplist[0][0]["resize"] == [int(z[f"case{i}_resized_shape"][1]), int(z[f"case{i}_resized_shape"][0]), w, h]
 
 
+def _seeds(first):
+    return [first] + [10_000 + first + k for k in range(int(os.environ.get("LMI_FUZZ_EXTRA", "0")))]
+
+
+@pytest.mark.parametrize("seed", _seeds(21))
 @pytest.mark.parametrize("fp16", [False, True])
-def test_random_geometries_against_oracle(ops, fp16):
-    rng = np.random.default_rng(21)
+def test_random_geometries_against_oracle(ops, fp16, seed):
+    rng = np.random.default_rng(seed)
     for it in range(24):
         h, w = int(rng.integers(2, 400)), int(rng.integers(2, 500))
         dh, dw = int(rng.integers(8, 300)), int(rng.integers(8, 300))
