@@ -326,6 +326,14 @@ def process_mask(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.Tensor,
     b, nm, mh, mw = proto.shape
     _, max_det, stride = det.shape
     h0, w0 = int(orig_hw[0]), int(orig_hw[1])
+    # ultralytics' scale_masks crops the letterbox pad off the prototype window before interpolating; for an extremely
+    # thin frame that window is empty and F.interpolate raises -- same exception type and wording here
+    gain = min(mh / h0, mw / w0)
+    pad_x, pad_y = (mw - w0 * gain) / 2, (mh - h0 * gain) / 2
+    wh_, ww_ = int(mh - pad_y) - int(pad_y), int(mw - pad_x) - int(pad_x)
+    if wh_ <= 0 or ww_ <= 0:
+        raise RuntimeError(f"Input and output sizes should be greater than 0, but got input (H: {max(wh_, 0)}, W: {max(ww_, 0)}) "
+                           f"output (H: {h0}, W: {w0})")
     ldt = {torch.uint8: LMI_U8, torch.float32: LMI_F32}[out_dtype]
     capacity = max(int(capacity), 1)
     if out is None:
