@@ -131,6 +131,7 @@ def test_rotated_nms_more_candidates_than_the_lds_sort_buffer():
     ref = OO.non_max_suppression_rotated(p, 0.0005, 0.3, nc=nc, max_det=300)
     for b in range(2):
         rows, ra, margin = ref[b]
-        assert margin > 2e-5 and len(ra) == 300
+        assert margin > 2e-5, "seed puts a decision on the threshold: pick another"
+        assert len(ra) == 300
         assert int(count[b]) == 300 and anchor[b].cpu().numpy().tolist() == ra.tolist()
         assert np.array_equal(det[b].cpu().numpy(), rows)

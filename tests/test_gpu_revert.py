@@ -86,7 +86,10 @@ def test_revert_masks_letterbox_undo_1080p(ops, dtype):
     # pad only: centred zero pad and centred crop
     padded = ops.revert_masks(got[:2], [{"pad": [-3, -4, -5, -6]}])
     assert padded.shape == (2, 1091, 1927)
-    assert torch.equal(padded[:, 5:5 + 1080, 3:3 + 1920], got[:2]) and padded.sum() == got[:2].sum()
+    assert torch.equal(padded[:, 5:5 + 1080, 3:3 + 1920], got[:2])
+    border = padded.clone()
+    border[:, 5:5 + 1080, 3:3 + 1920] = 0
+    assert not border.any()   # (comparing fp32 sums of the two shapes would depend on the reduction order)
     cropped = ops.revert_masks(got[:2], [{"pad": [10, 11, 20, 21]}])
     assert torch.equal(cropped, got[:2, 20:1080 - 21, 10:1920 - 11])
     with pytest.raises(ValueError):
