@@ -68,3 +68,20 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.lmi_preprocess_u8(None, 4, 4, 3, 12, None, 0, None) == -1
     assert lib.lmi_nms_v8(None, 1, 80, 0, 8400, 0.25, 0.45, 0, 300, 30000, 7680.0, None, None, None, None, 0, None) == -1
     assert lib.lmi_process_mask(None, 1, 32, 160, 160, None, 300, 38, None, None, 1080, 1920, None, 2, 10, None, None, 0, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No CPU fallback: without the built extension the loader raises at once, and so does everything that binds it
+    (hip_ops imports the loader at module import)."""
+    import importlib
+    import object_detectors_amd._lib as L
+    import object_detectors_amd.hip_ops as H   # with the real library, before the path is bent
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "liblmi_hip.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        L.load()
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        importlib.reload(H)
+    monkeypatch.undo()
+    importlib.reload(H)   # back to the real library for the tests that follow
+    assert H._L is L.load()
