@@ -295,7 +295,7 @@ def main():
     res = None
     if rank == 0:
         cpu = None
-        if args.cpu_images > 0:
+        if args.cpu_images > 0 and world == 1:   # the CPU leg is timed at N=1 only
             threads = min(16, os.cpu_count() or 1)
             ips, dt, n_done = cpu_baseline(cfg, frames, head, proto, min(args.cpu_images, B), threads, args.cpu_seconds)
             cpu = {"value": round(ips, 3), "unit": "images/s", "cores": threads, "kind": "port",
