@@ -235,6 +235,11 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
     if (sy < P.dst_h) {
       const int4 e = yt[sy];
       row = (slot & 1) ? e.y : e.x;
+      // a source row whose vertical weight is 0 contributes 0 to the fixed-point sum whatever it holds: it is not
+      // fetched (the lanes then multiply stale LDS bytes by 0).  Exact integer down-scales such as 1080p -> 640x360
+      // (fy = 3 dy + 1) need only one source row per output row this way: half the reads.
+      const uint32_t bw = (uint32_t)e.z;
+      if (((slot & 1) ? (bw >> 16) : (bw & 0xffffu)) == 0u) row = -1;
     }
     if (row >= 0) {
       const uint32_t goff = (uint32_t)((long long)row * stride + span_b0);
