@@ -222,12 +222,6 @@ __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay
   return ovr > thr;
 }
 
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int srclane) {
-  const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, srclane);
-  const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), srclane);
-  return ((uint64_t)hi << 32) | lo;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Class-parallel suppression.  With per-class NMS the class offset (cls * max_wh) moves the boxes of different
 // classes so far apart that they cannot intersect, PROVIDED the x-extent of all candidates together is below
