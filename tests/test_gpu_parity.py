@@ -55,6 +55,9 @@ LB_CASES = [  # (h, w, S_h, S_w)
     (54, 96, 64, 64), (1080, 1920, 640, 640), (960, 1280, 640, 640), (750, 1000, 640, 640), (800, 1333, 640, 640),
     (375, 500, 640, 640), (427, 640, 640, 640), (33, 77, 96, 128), (720, 1280, 1280, 1280), (641, 333, 640, 640),
     (100, 1000, 640, 640), (2160, 3840, 640, 640), (7, 5, 32, 32), (480, 640, 640, 640), (300, 300, 316, 316),
+    # exact integer scales: odd ones have a zero second weight (those source rows are not fetched), even ones 1/2, 1/2
+    (64, 64, 64, 64), (128, 128, 64, 64), (192, 192, 64, 64), (256, 256, 64, 64), (320, 320, 64, 64), (448, 448, 64, 64),
+    (21, 21, 63, 63), (180, 320, 64, 64),
 ]
 
 
