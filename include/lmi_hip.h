@@ -43,7 +43,7 @@ enum lmi_status {
 enum lmi_dtype { LMI_F32 = 0, LMI_F16 = 1, LMI_U8 = 2 };
 
 /* resampler of the letterbox entry: the fixed-point cv2.INTER_LINEAR (default) */
-enum lmi_resize_mode { LMI_RESIZE_CV2_LINEAR = 0, LMI_RESIZE_TORCH_BILINEAR = 1 };
+enum lmi_resize_mode { LMI_RESIZE_CV2_LINEAR = 0, LMI_RESIZE_TORCH_BILINEAR = 1, LMI_RESIZE_TORCH_BILINEAR_1T = 2 };
 
 #define LMI_MAX_DET_CAP 1024   /* largest max_det lmi_nms_v8 accepts */
 #define LMI_MAX_MASK_DIM 32    /* number of prototype channels (nm) the mask kernels are built for */
@@ -110,7 +110,9 @@ typedef struct lmi_frame {
  * and the content may overhang the destination.  Bit-exact against aten's CPU kernels of torch 2.10
  * on >= 2 threads (aten computes differently on exactly one thread; tests/golden/letterbox_torch.npz,
  * oracle/geometry.py; aten switches between two kernels at new_h + new_w = 128, so does this one, per
- * frame).  workspace is not used (may be NULL).
+ * frame).  LMI_RESIZE_TORCH_BILINEAR_1T is what the same helpers compute when torch runs on exactly ONE thread
+ * (torch.set_num_threads(1), OMP_NUM_THREADS=1): aten then takes its 4-weight kernel for every 3-channel frame.
+ * workspace is not used (may be NULL).
  */
 int64_t lmi_letterbox_workspace_bytes(int table_sets, int dst_h, int dst_w);
 int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, int batch,

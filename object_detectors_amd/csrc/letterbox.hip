@@ -40,6 +40,7 @@ struct LbParams {
   int2 *xtab;       // [sets][xw]     {source pixel or -1 (border column), a0 | a1 << 16}
   int4 *ytab;       // [sets][dst_h]  {source row 0, source row 1 (or -1,-1: border row), b0 | b1 << 16, 0}
   int xw;           // dst_w rounded up to 4
+  int torch_one_thread;  // torch flavour: aten's kernel choice on exactly one thread (always the 4-weight form)
 };
 
 // One axis of OpenCV's INTER_LINEAR table (resize.cpp, cv::hal::resize): see oracle/cv2_resize.py.
@@ -402,7 +403,9 @@ __global__ __launch_bounds__(256) void letterbox_torch_kernel(LbParams P) {
   int h, w, new_w, new_h, pad_l, pad_t;
   long long stride;
   frame_of(P, b, src, h, w, stride, new_w, new_h, pad_l, pad_t);
-  const bool weights4 = new_h + new_w <= 128;   // aten's choice between its two CPU kernels (3 channels, >= 2 threads)
+  // aten's choice between its two CPU kernels for a 3-channel frame: by output size on >= 2 threads, always the
+  // 4-weight form on one
+  const bool weights4 = P.torch_one_thread || new_h + new_w <= 128;
   const reg_t pv = TR::make(P.pad_value);
   reg_t out[3][4];
   const int dy = y - pad_t;
@@ -529,7 +532,7 @@ int check_common(const void *dst, int dst_h, int dst_w, int dst_dtype, int pad_v
   LMI_REQUIRE(dst_h > 0 && dst_w > 0, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: bad destination size %dx%d", dst_h, dst_w);
   LMI_REQUIRE(dst_dtype == LMI_F32 || dst_dtype == LMI_F16, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: dst_dtype must be LMI_F32 or LMI_F16");
   LMI_REQUIRE(pad_value >= 0 && pad_value <= 255, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: pad_value %d not in 0..255", pad_value);
-  LMI_REQUIRE(mode == LMI_RESIZE_CV2_LINEAR || mode == LMI_RESIZE_TORCH_BILINEAR, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: unknown resize mode %d", mode);
+  LMI_REQUIRE(mode == LMI_RESIZE_CV2_LINEAR || mode == LMI_RESIZE_TORCH_BILINEAR || mode == LMI_RESIZE_TORCH_BILINEAR_1T, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: unknown resize mode %d", mode);
   LMI_REQUIRE(lmi_is_aligned(dst, 16), LMI_ERR_ALIGNMENT, "lmi_letterbox_u8: dst must be 16-byte aligned");
   return LMI_OK;
 }
@@ -565,7 +568,7 @@ int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, 
   for (int i = 0; i < batch; ++i) {
     const lmi_frame &f = frames_host[i];
     rc = check_frame(reinterpret_cast<const void *>(f.src), f.h, f.w, f.row_stride, f.new_w, f.new_h, f.pad_l, f.pad_t, dst_h, dst_w, i,
-                     mode == LMI_RESIZE_TORCH_BILINEAR);
+                     mode != LMI_RESIZE_CV2_LINEAR);
     if (rc) return rc;
     int a = lds_pitch_for(f.w, f.new_w, 128), b = lds_pitch_for(f.w, f.new_w, 32);
     if (a > p128) p128 = a;
@@ -575,7 +578,8 @@ int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, 
   P.frames = frames_dev;
   P.dst = dst; P.dst_h = dst_h; P.dst_w = dst_w; P.pad_value = pad_value; P.swap_rb = swap_rb ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (mode == LMI_RESIZE_TORCH_BILINEAR)   // no tables: workspace is not used
+  P.torch_one_thread = mode == LMI_RESIZE_TORCH_BILINEAR_1T ? 1 : 0;
+  if (mode != LMI_RESIZE_CV2_LINEAR)   // no tables: workspace is not used
     return dst_dtype == LMI_F32 ? launch_letterbox_torch<float>(P, batch, s) : launch_letterbox_torch<__half>(P, batch, s);
   return dst_dtype == LMI_F32 ? launch_letterbox<float>(P, batch, batch, p128, p32, workspace, workspace_bytes, s)
                               : launch_letterbox<__half>(P, batch, batch, p128, p32, workspace, workspace_bytes, s);
@@ -601,7 +605,8 @@ int lmi_letterbox_u8_uniform(const void *src, int batch, int h, int w, int64_t r
   P.new_w = g[0]; P.new_h = g[1]; P.pad_l = g[2]; P.pad_t = g[4];
   P.dst = dst; P.dst_h = dst_h; P.dst_w = dst_w; P.pad_value = pad_value; P.swap_rb = swap_rb ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (mode == LMI_RESIZE_TORCH_BILINEAR)
+  P.torch_one_thread = mode == LMI_RESIZE_TORCH_BILINEAR_1T ? 1 : 0;
+  if (mode != LMI_RESIZE_CV2_LINEAR)
     return dst_dtype == LMI_F32 ? launch_letterbox_torch<float>(P, batch, s) : launch_letterbox_torch<__half>(P, batch, s);
   const int p128 = lds_pitch_for(w, g[0], 128), p32 = lds_pitch_for(w, g[0], 32);
   return dst_dtype == LMI_F32 ? launch_letterbox<float>(P, batch, 1, p128, p32, workspace, workspace_bytes, s)

@@ -100,7 +100,7 @@ def torch_letterbox_geometry(h: int, w: int, dst_h: int, dst_w: int, resize=None
 
 def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple[int, int], pad_value: int = 114,
               swap_rb: bool = False, fp16: bool = False, stretch: bool = False,
-              out: Optional[torch.Tensor] = None, mode: str = "cv2", resize=None):
+              out: Optional[torch.Tensor] = None, mode: str = "cv2", resize=None, torch_threads: Optional[int] = None):
     """Fused resize + centred pad + channel swap + /255 + NCHW.
 
     frames: a (B,H,W,3) uint8 tensor (uniform batch) or a sequence of (H,W,3) uint8 tensors of any
@@ -109,6 +109,8 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
     mode 'cv2': cv2.resize INTER_LINEAR (the callers' default chain); mode 'torch': the reference helpers
     `resize_image` + `fit_im_to_size` (fp32 bilinear, truncating cast; `resize=(H, W)` as the v1 runner's
     `--resize`, either side None; pads may be negative = centred crop; pad value 0 is the helpers' default).
+    torch_threads=1 reproduces what those helpers give when torch runs on exactly one thread (aten then picks
+    its other CPU kernel for 3-channel frames); any other value: the >= 2-thread result.
     """
     dst_h, dst_w = int(dst_hw[0]), int(dst_hw[1])
     tdt, ldt = _dt(fp16)
@@ -169,7 +171,7 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
         out = torch.empty((len(keep), 3, dst_h, dst_w), dtype=tdt, device=dev)
     ws = _ws.get(dev, "letterbox", int(_L.lmi_letterbox_workspace_bytes(len(keep), dst_h, dst_w)))
     check(_L.lmi_letterbox_u8(C.addressof(desc), ddev.data_ptr(), len(keep), out.data_ptr(), dst_h, dst_w, ldt,
-                              pad_value, int(swap_rb), 1 if mode == "torch" else 0, ws.data_ptr(), ws.numel(), _stream()))
+                              pad_value, int(swap_rb), (2 if torch_threads == 1 else 1) if mode == "torch" else 0, ws.data_ptr(), ws.numel(), _stream()))
     ddev.record_stream(torch.cuda.current_stream())
     return out, ops
 

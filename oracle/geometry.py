@@ -222,7 +222,7 @@ def revert_masks_to_origin(masks: np.ndarray, operations) -> np.ndarray:
 # reference's own two helpers run in the build container (tests/golden/make_golden_letterbox_torch.py), for torch
 # on >= 2 threads (aten picks another kernel, with other rounding, on exactly one thread).
 def letterbox_torch_u8(frame: np.ndarray, dst_h: int, dst_w: int, resize_w=None, resize_h=None, pad_value: int = 0,
-                       swap_rb: bool = False, fp16: bool = False):
+                       swap_rb: bool = False, fp16: bool = False, one_thread: bool = False):
     """uint8 (h,w,3) -> resize_image(W=resize_w, H=resize_h) (fp32 bilinear, truncating cast; a missing side keeps
     the aspect ratio with `int()`; both missing: the aspect-preserving fit into (dst_h, dst_w), the side that does
     not touch the frame truncated the same way) -> fit_im_to_size(H=dst_h, W=dst_w, value=pad_value) (centred pad,
@@ -235,7 +235,7 @@ def letterbox_torch_u8(frame: np.ndarray, dst_h: int, dst_w: int, resize_w=None,
         else:
             resize_w = dst_w
     new_w, new_h = resize_target(h, w, resize_w, resize_h)
-    small = resize_bilinear(frame, new_w, new_h)
+    small = resize_bilinear(frame, new_w, new_h, one_thread=one_thread)
     canvas, pl, pr, pt, pb = fit_im_to_size(small, W=dst_w, H=dst_h, value=pad_value)
     if swap_rb:
         canvas = canvas[:, :, ::-1]

@@ -49,6 +49,12 @@ def main():
         out[f"case{i}_resized_shape"] = np.array(im1.shape, dtype=np.int64)
         out[f"case{i}_pads"] = np.array([pl, pr, pt, pb], dtype=np.int64)
         out[f"case{i}_out"] = np.asarray(im2)
+        # the same chain with torch on ONE thread (aten then runs its other CPU kernel on 3-channel frames)
+        torch.set_num_threads(1)
+        im1t = pu.resize_image(im=im0, **kw)
+        im2t, *_ = pu.fit_im_to_size(im=im1t, H=ph, W=pw, value=value)
+        out[f"case{i}_out_1t"] = np.asarray(im2t)
+        torch.set_num_threads(8)
     np.savez_compressed(os.path.join(HERE, "letterbox_torch.npz"), **out)
     print("wrote letterbox_torch.npz", os.path.getsize(os.path.join(HERE, "letterbox_torch.npz")), "bytes")
 

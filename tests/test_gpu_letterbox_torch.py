@@ -32,6 +32,9 @@ def test_golden_reference_outputs(ops):
         assert out.shape == (1, 3, ph, pw) and out.dtype == torch.float32
         assert np.array_equal(out[0].cpu().numpy(), ref.transpose(2, 0, 1).astype(np.float32) / np.float32(255)), f"case {i}"
         assert oplist[0][1]["pad"] == [int(v) for v in z[f"case{i}_pads"]]
+        one, _ = ops.letterbox([torch.from_numpy(im).cuda()], (ph, pw), pad_value=val, mode="torch", resize=resize, torch_threads=1)
+        ref1 = z[f"case{i}_out_1t"]                               # the reference with torch.set_num_threads(1)
+        assert np.array_equal(one[0].cpu().numpy(), ref1.transpose(2, 0, 1).astype(np.float32) / np.float32(255)), f"case {i} (1 thread)"
         assert oplist[0][0]["resize"] == [int(z[f"case{i}_resized_shape"][1]), int(z[f"case{i}_resized_shape"][0]), w, h]
 
 
@@ -81,6 +84,20 @@ def test_batch_1080p_to_640_and_tensor_input(ops):
     for b, f in enumerate(small):
         want3, wops = OG.letterbox_torch_u8(f.cpu().numpy(), 640, 640, pad_value=0)
         assert ops3[b] == wops and np.array_equal(out3[b].cpu().numpy(), want3)
+
+
+def test_single_thread_variant_against_oracle(ops):
+    """torch_threads=1: aten's 4-weight kernel for every 3-channel frame, whatever the output size."""
+    rng = np.random.default_rng(24)
+    differs = 0
+    for h, w, dh, dw in ((480, 640, 360, 480), (270, 480, 256, 256), (1080, 1920, 1280, 1280), (61, 83, 64, 80)):
+        im = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        want, _ = OG.letterbox_torch_u8(im, dh, dw, pad_value=9, one_thread=True)
+        many, _ = OG.letterbox_torch_u8(im, dh, dw, pad_value=9)
+        got, _ = ops.letterbox([torch.from_numpy(im).cuda()], (dh, dw), pad_value=9, mode="torch", torch_threads=1)
+        assert np.array_equal(got[0].cpu().numpy(), want), (h, w, dh, dw)
+        differs += int((want != many).sum())
+    assert differs > 0   # the two thread regimes really are different results on these shapes
 
 
 def test_mode_validation(ops):
