@@ -38,6 +38,15 @@ def mask_crop_window(mh: int, mw: int, h0: int, w0: int):
     return top, bottom, left, right
 
 
+def crop_indicator(boxes: np.ndarray, h: int, w: int) -> np.ndarray:
+    """(n,h,w) bool: the factor `crop_mask` multiplies masks with (yolov5_trt.py:383-388): column index >= x1 and
+    < x2, row index >= y1 and < y2, indices and boxes compared in fp32.  Pinned by tests/golden/yolov5_helpers.npz."""
+    b = boxes.astype(F32)
+    xs = np.arange(w, dtype=F32)[None, None, :]
+    ys = np.arange(h, dtype=F32)[None, :, None]
+    return (xs >= b[:, 0, None, None]) & (xs < b[:, 2, None, None]) & (ys >= b[:, 1, None, None]) & (ys < b[:, 3, None, None])
+
+
 def process_mask_native(proto: np.ndarray, coef: np.ndarray, boxes: np.ndarray, shape) -> np.ndarray:
     """proto (32,mh,mw), coef (n,32), boxes (n,4) in original-image pixels, shape (H0,W0)
     -> (n,H0,W0) fp32 of 0./1."""

@@ -41,6 +41,20 @@ def xywh2xyxy(x: np.ndarray) -> np.ndarray:
     return out
 
 
+def box_iou(box1: np.ndarray, box2: np.ndarray, eps: float = 1e-7) -> np.ndarray:
+    """(N,4) x (M,4) xyxy -> (N,M) fp32 IoU, the in-tree `box_iou` (yolov5_trt.py:285-303): inter =
+    clamp(min(a2,b2) - max(a1,b1), 0).prod; inter / (area1 + area2 - inter + eps), every step in fp32.  With
+    eps = 0 this is the quotient `nms_greedy` thresholds (torchvision's kernel has no eps)."""
+    a = box1.astype(F32, copy=False)[:, None, :]
+    b = box2.astype(F32, copy=False)[None, :, :]
+    wh = np.maximum(np.minimum(a[..., 2:4], b[..., 2:4]) - np.maximum(a[..., 0:2], b[..., 0:2]), F32(0))
+    inter = wh[..., 0] * wh[..., 1]
+    area1 = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1])
+    area2 = (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return inter / (area1 + area2 - inter + F32(eps))
+
+
 def nms_greedy(boxes: np.ndarray, scores: np.ndarray, iou_thres: float) -> np.ndarray:
     """torchvision.ops.nms (CPU kernel) -> kept indices in score order."""
     n = boxes.shape[0]
@@ -71,6 +85,27 @@ def nms_greedy(boxes: np.ndarray, scores: np.ndarray, iou_thres: float) -> np.nd
             ovr = inter / (areas[i] + areas[i + 1 :] - inter)
             suppressed[i + 1 :] |= ovr.astype(np.float64) > thr
     return np.asarray(keep, dtype=np.int64)
+
+
+def decode_candidates(p: np.ndarray, conf_thres: float, nc: int, agnostic: bool = False, max_nms: int = 30000,
+                      max_wh: int = 7680):
+    """One image's head p (4+nc+nm, A) -> what the reference hands to `torchvision.ops.nms` and indexes afterwards
+    (yolov5_trt.py:243-266): (rows (n, 6+nm) sorted by descending score, anchors (n,), class-offset boxes (n,4)).
+    Pinned by tests/golden/yolov5_helpers.npz (the arguments the reference's own decode passes to the NMS call)."""
+    mi = 4 + nc
+    thr = F32(conf_thres)
+    cand = np.nonzero(p[4:mi].max(axis=0) > thr)[0]
+    x = np.ascontiguousarray(p[:, cand].T)
+    cls = x[:, 4:mi]
+    j = cls.argmax(axis=1) if len(x) else np.zeros((0,), np.int64)
+    conf = cls[np.arange(cls.shape[0]), j]
+    rows = np.concatenate([xywh2xyxy(x[:, :4]), conf[:, None], j[:, None].astype(F32), x[:, mi:]], axis=1)
+    sel = conf > thr
+    rows, anchors = rows[sel], cand[sel]
+    order = np.argsort(-rows[:, 4], kind="stable")[:max_nms]
+    rows, anchors = rows[order], anchors[order]
+    c = rows[:, 5:6] * F32(0 if agnostic else max_wh)
+    return rows, anchors, rows[:, :4] + c
 
 
 def non_max_suppression(
