@@ -48,6 +48,7 @@ enum lmi_resize_mode { LMI_RESIZE_CV2_LINEAR = 0, LMI_RESIZE_TORCH_BILINEAR = 1,
 #define LMI_MAX_DET_CAP 1024   /* largest max_det lmi_nms_v8 accepts */
 #define LMI_MAX_MASK_DIM 32    /* number of prototype channels (nm) the mask kernels are built for */
 #define LMI_MAX_POINT_OPS 16   /* longest operator list lmi_revert_points_f32 accepts */
+#define LMI_NMS_STATIC_BYTES (4 << 20) /* built-in workspace of lmi_nms_v8_static, per GPU */
 
 int lmi_version(void);
 const char *lmi_status_string(int status);
@@ -161,6 +162,20 @@ int lmi_nms_suppress(const float *pred, int batch, int nc, int nm, int anchors, 
                      int agnostic, int max_det, int max_nms, float max_wh, int rotated,
                      float *out_det, int32_t *out_count, int32_t *out_anchor, void *workspace,
                      int64_t workspace_bytes, void *stream);
+
+/* lmi_nms_v8 without a workspace argument, for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has NO counterpart in the reference: same
+ * arguments, kernels and results as lmi_nms_v8, but the workspace is a 4 MiB (LMI_NMS_STATIC_BYTES) device array
+ * built into the library -- every GPU the library runs on holds its own copy until the process ends -- and the
+ * call makes no hipMalloc / hipFree.  Sizes with lmi_nms_workspace_bytes(batch, anchors) > LMI_NMS_STATIC_BYTES
+ * (e.g. more than 11 images of 8400 anchors, or more than 2 of 33600) are rejected with LMI_ERR_LIMIT.  The
+ * workspace of the CURRENT device is used: call with the device current that owns `stream` and the buffers.  All
+ * calls on one GPU share that one array: calls that overlap on a GPU (two streams, two threads) race -- serialise
+ * them, or use lmi_nms_v8 with separate workspaces.
+ */
+int lmi_nms_v8_static(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres,
+                      double iou_thres, int agnostic, int max_det, int max_nms, float max_wh,
+                      float *out_det, int32_t *out_count, int32_t *out_anchor, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Finalize -- replaces, per image, `ops.scale_boxes(img.shape[2:], pred[:, :4], orig_img.shape)`

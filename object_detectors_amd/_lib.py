@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "liblmi_hip.so")
 
 LMI_F32, LMI_F16, LMI_U8 = 0, 1, 2
 LMI_MAX_DET_CAP = 1024
+LMI_NMS_STATIC_BYTES = 4 << 20
 
 
 class LmiError(RuntimeError):
@@ -51,6 +52,8 @@ SIGNATURES = {
     "lmi_nms_workspace_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "lmi_nms_v8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double, C.c_int, C.c_int,
                              C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "lmi_nms_v8_static": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double, C.c_int, C.c_int,
+                                    C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lmi_nms_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "lmi_nms_suppress": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_float,
                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

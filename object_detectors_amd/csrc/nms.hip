@@ -21,8 +21,14 @@
 //  finalize_boxes_kernel  one workgroup per image: scale/clip boxes in place, per-class threshold, ranks.
 //  finalize_slots_kernel  one workgroup per image: prefix of the keep counts -> dense global mask slots and their inverse map.
 #include <cmath>
+#include <mutex>
 
 #include "common.h"
+
+// Workspace of lmi_nms_v8_static (the entry point that allocates nothing): one copy per GPU, held until the process
+// ends.  In host code this name is only a handle for hipGetSymbolAddress -- the kernels get the per-device address
+// resolved in nms_device_state().
+static __device__ __align__(256) unsigned char scratch[LMI_NMS_STATIC_BYTES];
 
 namespace {
 
@@ -954,6 +960,49 @@ __global__ __launch_bounds__(1024) void finalize_obb_kernel(ObbParams F) {
 
 }  // namespace
 
+// Per-device set-up, done once per GPU on the first NMS call made with that GPU current: the largest dynamic LDS size
+// either sort kernel may be launched with (setting the attribute does not change the occupancy of smaller launches)
+// and the device address of this GPU's copy of `scratch`.
+constexpr int kMaxDevices = 64;
+struct NmsDeviceState {
+  bool ready = false;
+  void *scratch_ptr = nullptr;
+};
+static std::mutex g_nms_dev_mutex;
+static NmsDeviceState g_nms_dev[kMaxDevices];
+
+constexpr size_t nms_lds_small(int lds_keys, int max_det) {
+  return (size_t)lds_keys * 8 + 4 * 6 * (size_t)((max_det + 1) & ~1) + 64 * 8 + 64 * 4 + 16;
+}
+constexpr size_t nms_lds_rot_head(int lds_keys, int max_det) { return (size_t)lds_keys * 8 + 4 * (size_t)((max_det + 1) & ~1) + 4 * 17 + 16; }
+constexpr size_t kNmsLdsMax = ((nms_lds_small(kSortLdsCap, LMI_MAX_DET_CAP) + 15) & ~(size_t)15) + (size_t)kSortLdsCap * 16;
+constexpr size_t kNmsLdsRotMax = ((nms_lds_rot_head(kSortLdsCap, LMI_MAX_DET_CAP) + 15) & ~(size_t)15) + (size_t)kSortLdsCap * (16 + 8);
+static_assert(kNmsLdsMax <= 160 * 1024 && kNmsLdsRotMax <= 160 * 1024, "sort kernels must fit the 160 KiB LDS of a gfx950 CU");
+
+static int nms_device_state(NmsDeviceState **out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    lmi_set_error("lmi_nms: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+    return LMI_ERR_NO_DEVICE;
+  }
+  std::lock_guard<std::mutex> lock(g_nms_dev_mutex);
+  NmsDeviceState &D = g_nms_dev[dev];
+  if (!D.ready) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_suppress), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNmsLdsMax);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_rotated), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNmsLdsRotMax);
+    if (e != hipSuccess) { lmi_set_error("lmi_nms: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LMI_ERR_LAUNCH; }
+    void *ptr = nullptr;
+    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || ptr == nullptr) { lmi_set_error("lmi_nms: hipGetSymbolAddress(scratch): %s", hipGetErrorString(e)); return LMI_ERR_LAUNCH; }
+    D.scratch_ptr = ptr;
+    D.ready = true;
+  }
+  *out = &D;
+  return LMI_OK;
+}
+
 extern "C" {
 
 int64_t lmi_nms_workspace_bytes(int batch, int anchors) {
@@ -1022,6 +1071,9 @@ static int nms_suppress(const NmsCall &C, const float *pred, int batch, int nc, 
   // nms_rotated compares `ious.max(0) < threshold` in fp32 (tensor vs Python float): the threshold rounded to fp32.
   float thr = (float)iou_thres;
   if (!rotated && (double)thr > iou_thres) thr = std::nextafterf(thr, -INFINITY);
+  NmsDeviceState *D = nullptr;
+  int rc0 = nms_device_state(&D);   // first call on this GPU: LDS limits of the sort kernels
+  if (rc0) return rc0;
 
   SortNmsParams S;
   S.pred = pred; S.nc = nc; S.nm = nm; S.A = anchors; S.iou_thr = thr; S.agnostic = agnostic ? 1 : 0;
@@ -1031,17 +1083,13 @@ static int nms_suppress(const NmsCall &C, const float *pred, int batch, int nc, 
   S.scd = reinterpret_cast<float2 *>(C.ws + C.L.off_cd);
   if (rotated) {
     LMI_REQUIRE(nm >= 1, LMI_ERR_BAD_ARG, "lmi_nms_v8_rotated: the angle must be the last of nm >= 1 extra channels");
-    const size_t head = (size_t)S.lds_keys * 8 + 4 * (size_t)((max_det + 1) & ~1) + 4 * 17 + 16;
-    S.lbox_off = (int)((head + 15) & ~(size_t)15);
+    S.lbox_off = (int)((nms_lds_rot_head(S.lds_keys, max_det) + 15) & ~(size_t)15);
     const size_t lds_rot = (size_t)S.lbox_off + (size_t)S.lds_keys * (16 + 8);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_rotated), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rot);
     hipLaunchKernelGGL(nms_sort_rotated, dim3(batch), dim3(kSortThreads), lds_rot, C.s, S);
     return lmi_check_launch("nms_sort_rotated");
   }
-  const size_t lds_small = (size_t)S.lds_keys * 8 + 4 * 6 * (size_t)((max_det + 1) & ~1) + 64 * 8 + 64 * 4 + 16;
-  S.lbox_off = (int)((lds_small + 15) & ~(size_t)15);
+  S.lbox_off = (int)((nms_lds_small(S.lds_keys, max_det) + 15) & ~(size_t)15);
   const size_t lds = (size_t)S.lbox_off + (size_t)S.lds_keys * 16;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_suppress), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(nms_sort_suppress, dim3(batch), dim3(kSortThreads), lds, C.s, S);
   return lmi_check_launch("nms_sort_suppress");
 }
@@ -1083,6 +1131,23 @@ int lmi_nms_v8(const float *pred, int batch, int nc, int nm, int anchors, float 
                int32_t *out_anchor, void *workspace, int64_t workspace_bytes, void *stream) {
   return nms_common(pred, batch, nc, nm, anchors, conf_thres, iou_thres, agnostic, max_det, max_nms, max_wh, out_det, out_count,
                     out_anchor, workspace, workspace_bytes, stream, 0);
+}
+
+int lmi_nms_v8_static(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres, double iou_thres,
+                      int agnostic, int max_det, int max_nms, float max_wh, float *out_det, int32_t *out_count,
+                      int32_t *out_anchor, void *stream) {
+  LMI_REQUIRE(batch > 0 && anchors > 0, LMI_ERR_BAD_ARG, "lmi_nms_v8_static: bad shape batch=%d anchors=%d", batch, anchors);
+  const int64_t need = lmi_nms_workspace_bytes(batch, anchors);
+  LMI_REQUIRE(need <= (int64_t)LMI_NMS_STATIC_BYTES, LMI_ERR_LIMIT,
+              "lmi_nms_v8_static: batch %d x %d anchors needs %lld bytes of workspace, the built-in one holds %lld "
+              "(use lmi_nms_v8 with a caller-allocated workspace)", batch, anchors, (long long)need, (long long)LMI_NMS_STATIC_BYTES);
+  NmsDeviceState *D = nullptr;
+  int rc = nms_device_state(&D);
+  if (rc) return rc;
+  // same kernels as lmi_nms_v8, on this GPU's copy of `scratch`; nms_decode clears the candidate counts, every
+  // other part of the workspace is written before it is read
+  return nms_common(pred, batch, nc, nm, anchors, conf_thres, iou_thres, agnostic, max_det, max_nms, max_wh, out_det, out_count,
+                    out_anchor, D->scratch_ptr, (int64_t)LMI_NMS_STATIC_BYTES, stream, 0);
 }
 
 int lmi_nms_v8_rotated(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres, double iou_thres,
