@@ -163,6 +163,45 @@ int lmi_nms_suppress(const float *pred, int batch, int nc, int nm, int anchors, 
                      float *out_det, int32_t *out_count, int32_t *out_anchor, void *workspace,
                      int64_t workspace_bytes, void *stream);
 
+/* The general form of the three calls above ("_ex"): same reference lines, same kernels, plus
+ *   pred_dtype  LMI_F32 or LMI_F16: the head of an `fp16=True` model (object_detectors/yolov8_lmi/model.py:68,132)
+ *               is read as it is; every value is promoted to fp32 (exactly) and all comparisons and box arithmetic
+ *               run in fp32 -- the result of `pred.float()` + the fp32 call, without that extra pass over the head.
+ *               (The reference would run ultralytics' NMS on the fp16 tensor itself, where `cls * 7680` overflows to
+ *               inf from class 9 on and the score threshold is rounded to fp16: deliberately not reproduced.)
+ *   rotated     != 0: oriented boxes (lmi_nms_v8_rotated)
+ *   fin         NULL, or the arguments of lmi_finalize_detections (below): `ops.scale_boxes` + clip, the per-class
+ *               threshold and the survivors' dense ranks (object_detectors/yolov8_lmi/model.py:222-232) then run in
+ *               the suppression kernel's epilogue -- rows leave in original-image space and keep / keep_count are
+ *               written by the same launch; when mask_slot / slot_base are asked for, one small launch turns the
+ *               per-image ranks into dense global slots (without slots, e.g. detection models: no extra launch).
+ *               Results are identical to lmi_nms_v8 followed by lmi_finalize_detections.  Not with rotated != 0.
+ */
+typedef struct lmi_finalize_args {
+  int32_t model_h, model_w;        /* network input size (img.shape[2:]) */
+  int32_t uniform_h0, uniform_w0;  /* original size of every image when orig_hw is NULL */
+  const int32_t *orig_hw;          /* [device] int32 (batch,2) = (H0,W0) per image, or NULL */
+  int32_t pad_round;               /* 1 = ultralytics 8.3.x round(pad - 0.1); 0 = un-rounded pad */
+  int32_t reserved;
+  const double *thres;             /* [device] double (nc) per-class thresholds, or NULL -> uniform_thres */
+  double uniform_thres;
+  uint8_t *keep;                   /* [device] uint8 (batch, max_det) */
+  int32_t *keep_count;             /* [device] int32 (batch) */
+  int32_t *mask_slot;              /* [device] int32 (batch, max_det), may be NULL */
+  int32_t *slot_map;               /* [device] int32 (batch*max_det), may be NULL */
+  int32_t *slot_base;              /* [device] int32 (batch+1), may be NULL */
+} lmi_finalize_args;
+int lmi_nms_v8_ex(const void *pred, int pred_dtype, int batch, int nc, int nm, int anchors, float conf_thres,
+                  double iou_thres, int agnostic, int max_det, int max_nms, float max_wh, int rotated,
+                  const lmi_finalize_args *fin, float *out_det, int32_t *out_count, int32_t *out_anchor,
+                  void *workspace, int64_t workspace_bytes, void *stream);
+int lmi_nms_decode_ex(const void *pred, int pred_dtype, int batch, int nc, int nm, int anchors, float conf_thres,
+                      void *workspace, int64_t workspace_bytes, void *stream);
+int lmi_nms_suppress_ex(const void *pred, int pred_dtype, int batch, int nc, int nm, int anchors, double iou_thres,
+                        int agnostic, int max_det, int max_nms, float max_wh, int rotated,
+                        const lmi_finalize_args *fin, float *out_det, int32_t *out_count, int32_t *out_anchor,
+                        void *workspace, int64_t workspace_bytes, void *stream);
+
 /* lmi_nms_v8 without a workspace argument, for callers that cannot allocate device memory (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  It has NO counterpart in the reference: same
  * arguments, kernels and results as lmi_nms_v8, but the workspace is a 4 MiB (LMI_NMS_STATIC_BYTES) device array

@@ -27,6 +27,13 @@ class lmi_frame(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class lmi_finalize_args(C.Structure):
+    _fields_ = [("model_h", C.c_int32), ("model_w", C.c_int32), ("uniform_h0", C.c_int32), ("uniform_w0", C.c_int32),
+                ("orig_hw", C.c_void_p), ("pad_round", C.c_int32), ("reserved", C.c_int32), ("thres", C.c_void_p),
+                ("uniform_thres", C.c_double), ("keep", C.c_void_p), ("keep_count", C.c_void_p), ("mask_slot", C.c_void_p),
+                ("slot_map", C.c_void_p), ("slot_base", C.c_void_p)]
+
+
 class lmi_point_op(C.Structure):
     _fields_ = [("kind", C.c_int32), ("x", C.c_float), ("y", C.c_float)]
 
@@ -52,6 +59,14 @@ SIGNATURES = {
     "lmi_nms_workspace_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "lmi_nms_v8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double, C.c_int, C.c_int,
                              C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "lmi_nms_v8_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double, C.c_int, C.c_int,
+                                C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                C.c_void_p]),
+    "lmi_nms_decode_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int64,
+                                    C.c_void_p]),
+    "lmi_nms_suppress_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
+                                      C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_void_p]),
     "lmi_nms_v8_static": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double, C.c_int, C.c_int,
                                     C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lmi_nms_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -20,6 +20,8 @@
 //                     in one wave.  Both stop at max_det keeps.
 //  finalize_boxes_kernel  one workgroup per image: scale/clip boxes in place, per-class threshold, ranks.
 //  finalize_slots_kernel  one workgroup per image: prefix of the keep counts -> dense global mask slots and their inverse map.
+#include <hip/hip_fp16.h>
+
 #include <cmath>
 #include <mutex>
 
@@ -52,6 +54,21 @@ __device__ __forceinline__ float sortable2f(uint32_t s) {
   return __uint_as_float(u);
 }
 
+// Head element -> fp32.  fp16 heads (`fp16=True` models, object_detectors/yolov8_lmi/model.py:68,132) are promoted
+// value by value -- an exact conversion -- and every comparison and box operation runs in fp32: the same result as
+// `pred.float()` followed by the fp32 path, without that extra pass over the head.
+__device__ __forceinline__ float ldf(const float *p, size_t i) { return p[i]; }
+__device__ __forceinline__ float ldf(const __half *p, size_t i) { return __half2float(p[i]); }
+__device__ __forceinline__ void ld4(const float *p, float e[4]) {
+  const float4 v = *reinterpret_cast<const float4 *>(p);
+  e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w;
+}
+__device__ __forceinline__ void ld4(const __half *p, float e[4]) {
+  const uint2 v = *reinterpret_cast<const uint2 *>(p);
+  const __half2 lo = *reinterpret_cast<const __half2 *>(&v.x), hi = *reinterpret_cast<const __half2 *>(&v.y);
+  e[0] = __low2float(lo); e[1] = __high2float(lo); e[2] = __low2float(hi); e[3] = __high2float(hi);
+}
+
 struct NmsLayout {
   size_t off_count, off_keys, off_cls, off_sbox, off_cd, total;
   int P;
@@ -76,8 +93,8 @@ NmsLayout nms_layout(int batch, int anchors) {
 // Workgroup = 4 waves over the SAME 64*VEC anchors; wave w scans one quarter of the class rows (4x the loads in
 // flight of a one-wave-per-anchor-group layout), wave 0 merges the quarters in class order (strict >, so the
 // first maximal class wins as in torch.max) and compacts the candidates.
-template <int VEC>
-__global__ __launch_bounds__(256) void nms_decode_filter(const float *__restrict__ pred, int nc, int nm, int A, float conf,
+template <int VEC, typename InT>
+__global__ __launch_bounds__(256) void nms_decode_filter(const InT *__restrict__ pred, int nc, int nm, int A, float conf,
                                                         uint64_t *__restrict__ keys, int P, int *__restrict__ cls_of,
                                                         int *__restrict__ cand_count) {
   __shared__ float sbest[3][64 * VEC];
@@ -86,7 +103,7 @@ __global__ __launch_bounds__(256) void nms_decode_filter(const float *__restrict
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int a0 = (blockIdx.x * 64 + lane) * VEC;
   const int C = 4 + nc + nm;
-  const float *cls = pred + ((size_t)b * C + 4) * A;
+  const InT *cls = pred + ((size_t)b * C + 4) * A;
   const int cpart = (nc + 3) >> 2;
   const int c0 = wave * cpart, c1 = min(nc, c0 + cpart);
   float best[VEC];
@@ -96,21 +113,20 @@ __global__ __launch_bounds__(256) void nms_decode_filter(const float *__restrict
   for (int k = 0; k < VEC; ++k) { best[k] = -INFINITY; bi[k] = c0; }
   if (valid && c0 < c1) {
     if constexpr (VEC == 4) {
-      float4 v = *reinterpret_cast<const float4 *>(cls + (size_t)c0 * A + a0);
-      best[0] = v.x; best[1] = v.y; best[2] = v.z; best[3] = v.w;
+      ld4(cls + (size_t)c0 * A + a0, best);
 #pragma unroll 8
       for (int c = c0 + 1; c < c1; ++c) {
-        v = *reinterpret_cast<const float4 *>(cls + (size_t)c * A + a0);
-        const float e[4] = {v.x, v.y, v.z, v.w};
+        float e[4];
+        ld4(cls + (size_t)c * A + a0, e);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (e[k] > best[k]) { best[k] = e[k]; bi[k] = c; }
       }
     } else {
-      best[0] = cls[(size_t)c0 * A + a0];
+      best[0] = ldf(cls, (size_t)c0 * A + a0);
 #pragma unroll 8
       for (int c = c0 + 1; c < c1; ++c) {
-        const float e = cls[(size_t)c * A + a0];
+        const float e = ldf(cls, (size_t)c * A + a0);
         if (e > best[0]) { best[0] = e; bi[0] = c; }
       }
     }
@@ -402,8 +418,47 @@ __device__ bool class_parallel_nms(const CpScratch &C, const float4 *lbox, int n
   return true;
 }
 
+struct FinalizeParams {
+  float *det;
+  const int *count;
+  int batch, max_det, det_stride, nc;
+  int model_h, model_w;
+  const int *orig_hw;
+  int uh0, uw0;
+  int pad_round;
+  const double *thres;
+  double uniform_thres;
+  uint8_t *keep;
+  int *keep_count;
+  int *mask_slot;
+  int *slot_map;
+  int *slot_base;
+};
+
+// Python round(): nearest, ties to even
+__device__ __forceinline__ double py_round(double x) { return rint(x); }
+
+// ops.scale_boxes: gain / pad are Python floats (fp64), applied to the fp32 tensor with IEEE division
+struct BoxScale {
+  float px, py, gain, w0, h0;
+};
+__device__ __forceinline__ BoxScale box_scale(const FinalizeParams &F, int b) {
+  const int h0 = F.orig_hw ? F.orig_hw[2 * b] : F.uh0;
+  const int w0 = F.orig_hw ? F.orig_hw[2 * b + 1] : F.uw0;
+  const double gh = (double)F.model_h / (double)h0, gw = (double)F.model_w / (double)w0;
+  const double gain = gh < gw ? gh : gw;
+  double px = ((double)F.model_w - (double)w0 * gain) / 2.0;
+  double py = ((double)F.model_h - (double)h0 * gain) / 2.0;
+  if (F.pad_round) { px = py_round(px - 0.1); py = py_round(py - 0.1); }
+  return BoxScale{(float)px, (float)py, (float)gain, (float)w0, (float)h0};
+}
+__device__ __forceinline__ float scale_x(const BoxScale &s, float x) { return fminf(fmaxf((x - s.px) / s.gain, 0.0f), s.w0); }
+__device__ __forceinline__ float scale_y(const BoxScale &s, float y) { return fminf(fmaxf((y - s.py) / s.gain, 0.0f), s.h0); }
+
 struct SortNmsParams {
-  const float *pred;
+  const void *pred;   // fp32 or fp16 head, see the kernels' InT
+  int fin;            // != 0: finalize (F) in the epilogue -- lmi_nms_v8_finalize
+  FinalizeParams F;
   int nc, nm, A;
   float iou_thr;  // effective fp32 threshold (see host side)
   int agnostic, max_det, max_nms;
@@ -421,6 +476,44 @@ struct SortNmsParams {
   float2 *scd;   // rotated: covariance c and determinant per sorted candidate (global copy)
 };
 
+// Fused per-image half of `lmi_finalize_detections` (finalize_boxes_kernel is the stand-alone form): the per-class
+// threshold and the ranks of image b's K kept rows (the boxes were scaled while the rows were written).  The prefix
+// over the images that turns ranks into dense global mask slots stays a launch of its own (finalize_slots_kernel):
+// doing it here in "whichever workgroup finishes last" needs device-scope fences, and on this multi-XCD part those
+// write back and invalidate the L2s -- measured: the fused call went from 72 to 93 us and the letterbox running
+// beside it from 100 to 158 us.  All kSortThreads lanes call this.  kpos / keys may live at the start of the LDS,
+// where `lds` points: they are read into registers before `lds` is written.
+__device__ void finalize_epilogue(const SortNmsParams &S, int b, int K, const int *kpos, const uint64_t *keys, int *lds) {
+  const FinalizeParams &F = S.F;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = kSortThreads / 64;
+  bool k = false;
+  if (tid < K) {
+    const uint64_t key = keys[kpos[tid]];
+    const uint32_t anchor = ~(uint32_t)key;
+    const float conf = sortable2f((uint32_t)(key >> 32));
+    const int c = S.cls_of[(size_t)b * S.A + anchor];
+    const double t = F.thres ? ((c >= 0 && c < F.nc) ? F.thres[c] : 1.0) : F.uniform_thres;
+    k = (double)conf > t;
+  }
+  __syncthreads();   // kpos / keys (possibly at the start of the LDS) are in registers now
+  const uint64_t mask = __ballot(k);
+  if (lane == 0) lds[wave] = __builtin_popcountll(mask);
+  __syncthreads();
+  int before = 0, total = 0;
+  for (int w = 0; w < NW; ++w) {
+    const int t = lds[w];
+    if (w < wave) before += t;
+    total += t;
+  }
+  if (tid < F.max_det) {
+    F.keep[(size_t)b * F.max_det + tid] = k ? 1 : 0;
+    if (F.mask_slot) F.mask_slot[(size_t)b * F.max_det + tid] = k ? before + __builtin_popcountll(mask & ((1ull << lane) - 1ull)) : -1;
+  }
+  if (tid == 0) F.keep_count[b] = total;
+}
+
+template <typename InT>
 __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams S) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t *lkeys = reinterpret_cast<uint64_t *>(smem);
@@ -440,13 +533,14 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int A = S.A, C = 4 + S.nc + S.nm;
-  const float *pb = S.pred + (size_t)b * C * A;
+  const InT *pb = reinterpret_cast<const InT *>(S.pred) + (size_t)b * C * A;
   uint64_t *gkeys = S.keys + (size_t)b * S.P;
   float4 *sbox = S.sbox + (size_t)b * A;
 
   const int n = min(S.cand_count[b], A);
   if (n == 0) {
     if (tid == 0) S.out_count[b] = 0;
+    if (S.fin) finalize_epilogue(S, b, 0, nullptr, nullptr, reinterpret_cast<int *>(smem));
     return;
   }
   const int P2 = next_pow2(n);
@@ -476,7 +570,7 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
   for (int i = tid; i < n_eff; i += kSortThreads) {
     const uint64_t key = in_lds ? lkeys[i] : gkeys[i];
     const uint32_t anchor = ~(uint32_t)key;
-    const float cx = pb[anchor], cy = pb[(size_t)A + anchor], w = pb[(size_t)2 * A + anchor], h = pb[(size_t)3 * A + anchor];
+    const float cx = ldf(pb, anchor), cy = ldf(pb, (size_t)A + anchor), w = ldf(pb, (size_t)2 * A + anchor), h = ldf(pb, (size_t)3 * A + anchor);
     const float hw = w / 2.0f, hh = h / 2.0f;
     const int cls = S.agnostic ? 0 : S.cls_of[(size_t)b * A + anchor];
     const float c = S.agnostic ? 0.0f : (float)cls * S.max_wh;
@@ -609,6 +703,8 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
   if (tid == 0) S.out_count[b] = K;
   const int row = 6 + S.nm;
   float *od = S.out_det + (size_t)b * S.max_det * row;
+  BoxScale bs{};
+  if (S.fin) bs = box_scale(S.F, b);   // fused `ops.scale_boxes` + clip: the rows leave in original-image space
   for (int e = tid; e < K * row; e += kSortThreads) {
     const int t = e / row, col = e - t * row;
     const int pos = kpos[t];
@@ -616,18 +712,23 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
     const uint32_t anchor = ~(uint32_t)key;
     float v;
     if (col < 4) {
-      const float c0 = pb[(size_t)(col & 1) * A + anchor];
-      const float half = pb[(size_t)(2 + (col & 1)) * A + anchor] / 2.0f;
+      const float c0 = ldf(pb, (size_t)(col & 1) * A + anchor);
+      const float half = ldf(pb, (size_t)(2 + (col & 1)) * A + anchor) / 2.0f;
       v = (col < 2) ? (c0 - half) : (c0 + half);
+      if (S.fin) v = (col & 1) ? scale_y(bs, v) : scale_x(bs, v);
     } else if (col == 4) {
       v = sortable2f((uint32_t)(key >> 32));
     } else if (col == 5) {
       v = (float)S.cls_of[(size_t)b * A + anchor];
     } else {
-      v = pb[(size_t)(4 + S.nc + (col - 6)) * A + anchor];
+      v = ldf(pb, (size_t)(4 + S.nc + (col - 6)) * A + anchor);
     }
     od[e] = v;
     if (col == 0) S.out_anchor[(size_t)b * S.max_det + t] = (int)anchor;
+  }
+  if (S.fin) {
+    __syncthreads();   // every reader of the sort buffers is done: the epilogue reuses the start of the LDS
+    finalize_epilogue(S, b, K, kpos, in_lds ? lkeys : gkeys, reinterpret_cast<int *>(smem));
   }
 }
 
@@ -653,6 +754,7 @@ __device__ __forceinline__ float probiou(float x1, float y1, float a1, float b1,
   return 1.0f - hd;
 }
 
+template <typename InT>
 __global__ __launch_bounds__(kSortThreads) void nms_sort_rotated(SortNmsParams S) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t *lkeys = reinterpret_cast<uint64_t *>(smem);
@@ -665,7 +767,7 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_rotated(SortNmsParams S
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int A = S.A, C = 4 + S.nc + S.nm;
-  const float *pb = S.pred + (size_t)b * C * A;
+  const InT *pb = reinterpret_cast<const InT *>(S.pred) + (size_t)b * C * A;
   uint64_t *gkeys = S.keys + (size_t)b * S.P;
 
   const int n = min(S.cand_count[b], A);
@@ -691,8 +793,8 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_rotated(SortNmsParams S
 
   for (int i = tid; i < n_eff; i += kSortThreads) {
     const uint32_t anchor = ~(uint32_t)keys[i];
-    const float x = pb[anchor], y = pb[(size_t)A + anchor], w = pb[(size_t)2 * A + anchor], h = pb[(size_t)3 * A + anchor];
-    const float ang = pb[(size_t)(C - 1) * A + anchor];
+    const float x = ldf(pb, anchor), y = ldf(pb, (size_t)A + anchor), w = ldf(pb, (size_t)2 * A + anchor), h = ldf(pb, (size_t)3 * A + anchor);
+    const float ang = ldf(pb, (size_t)(C - 1) * A + anchor);
     const float off = S.agnostic ? 0.0f : (float)S.cls_of[(size_t)b * A + anchor] * S.max_wh;
     const float w2 = w * w / 12.0f, h2 = h * h / 12.0f;
     const float cs = cosf(ang), sn = sinf(ang);
@@ -751,35 +853,16 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_rotated(SortNmsParams S
     const uint64_t key = keys[kpos[t]];
     const uint32_t anchor = ~(uint32_t)key & 0x7fffffffu;
     float v;
-    if (col < 4) v = pb[(size_t)col * A + anchor];
+    if (col < 4) v = ldf(pb, (size_t)col * A + anchor);
     else if (col == 4) v = sortable2f((uint32_t)(key >> 32));
     else if (col == 5) v = (float)S.cls_of[(size_t)b * A + anchor];
-    else v = pb[(size_t)(4 + S.nc + (col - 6)) * A + anchor];
+    else v = ldf(pb, (size_t)(4 + S.nc + (col - 6)) * A + anchor);
     od[e] = v;
     if (col == 0) S.out_anchor[(size_t)b * S.max_det + t] = (int)anchor;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-struct FinalizeParams {
-  float *det;
-  const int *count;
-  int batch, max_det, det_stride, nc;
-  int model_h, model_w;
-  const int *orig_hw;
-  int uh0, uw0;
-  int pad_round;
-  const double *thres;
-  double uniform_thres;
-  uint8_t *keep;
-  int *keep_count;
-  int *mask_slot;
-  int *slot_map;
-  int *slot_base;
-};
-
-// Python round(): nearest, ties to even
-__device__ __forceinline__ double py_round(double x) { return rint(x); }
 
 // grid = batch, block = max_det rounded up to a wave (<= 1024): lane i owns detection i of image b.
 __global__ __launch_bounds__(1024) void finalize_boxes_kernel(FinalizeParams F) {
@@ -787,28 +870,17 @@ __global__ __launch_bounds__(1024) void finalize_boxes_kernel(FinalizeParams F) 
   const int b = blockIdx.x;
   const int i = threadIdx.x, lane = i & 63, wave = i >> 6, nwaves = blockDim.x >> 6;
   const int n = min(F.count[b], F.max_det);
-  const int h0 = F.orig_hw ? F.orig_hw[2 * b] : F.uh0;
-  const int w0 = F.orig_hw ? F.orig_hw[2 * b + 1] : F.uw0;
   bool k = false;
   if (i < n) {
-    // ops.scale_boxes: gain / pad are Python floats (fp64), applied to the fp32 tensor with IEEE division
-    const double gh = (double)F.model_h / (double)h0, gw = (double)F.model_w / (double)w0;
-    const double gain = gh < gw ? gh : gw;
-    double px = ((double)F.model_w - (double)w0 * gain) / 2.0;
-    double py = ((double)F.model_h - (double)h0 * gain) / 2.0;
-    if (F.pad_round) { px = py_round(px - 0.1); py = py_round(py - 0.1); }
-    const float fpx = (float)px, fpy = (float)py, fgain = (float)gain;
-    const float fw0 = (float)w0, fh0 = (float)h0;
+    const BoxScale bs = box_scale(F, b);
     float *d = F.det + ((size_t)b * F.max_det + i) * F.det_stride;
-    float x1 = d[0], y1 = d[1], x2 = d[2], y2 = d[3];
+    const float x1 = d[0], y1 = d[1], x2 = d[2], y2 = d[3];
     const float conf = d[4];
     const int c = (int)d[5];
-    x1 = (x1 - fpx) / fgain; y1 = (y1 - fpy) / fgain;
-    x2 = (x2 - fpx) / fgain; y2 = (y2 - fpy) / fgain;
-    d[0] = fminf(fmaxf(x1, 0.0f), fw0);
-    d[1] = fminf(fmaxf(y1, 0.0f), fh0);
-    d[2] = fminf(fmaxf(x2, 0.0f), fw0);
-    d[3] = fminf(fmaxf(y2, 0.0f), fh0);
+    d[0] = scale_x(bs, x1);
+    d[1] = scale_y(bs, y1);
+    d[2] = scale_x(bs, x2);
+    d[3] = scale_y(bs, y2);
     const double t = F.thres ? ((c >= 0 && c < F.nc) ? F.thres[c] : 1.0) : F.uniform_thres;
     k = (double)conf > t;
   }
@@ -989,9 +1061,13 @@ static int nms_device_state(NmsDeviceState **out) {
   std::lock_guard<std::mutex> lock(g_nms_dev_mutex);
   NmsDeviceState &D = g_nms_dev[dev];
   if (!D.ready) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_suppress), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNmsLdsMax);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_suppress<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNmsLdsMax);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_rotated), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNmsLdsRotMax);
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_suppress<__half>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNmsLdsMax);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_rotated<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNmsLdsRotMax);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_rotated<__half>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNmsLdsRotMax);
     if (e != hipSuccess) { lmi_set_error("lmi_nms: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LMI_ERR_LAUNCH; }
     void *ptr = nullptr;
     e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
@@ -1018,11 +1094,13 @@ struct NmsCall {
   int *cls_of;
   float4 *sbox;
   unsigned char *ws;
+  int half;   // head dtype: 0 fp32, 1 fp16
 };
 
-static int nms_check(const float *pred, int batch, int nc, int nm, int anchors, void *workspace, int64_t workspace_bytes,
+static int nms_check(const void *pred, int pred_dtype, int batch, int nc, int nm, int anchors, void *workspace, int64_t workspace_bytes,
                      void *stream, NmsCall &C) {
   LMI_REQUIRE(pred && workspace, LMI_ERR_BAD_ARG, "lmi_nms_v8: NULL pointer");
+  LMI_REQUIRE(pred_dtype == LMI_F32 || pred_dtype == LMI_F16, LMI_ERR_BAD_ARG, "lmi_nms_v8: pred_dtype must be LMI_F32 or LMI_F16");
   LMI_REQUIRE(batch > 0 && batch <= 65535 && nc > 0 && nm >= 0 && anchors > 0, LMI_ERR_BAD_ARG,
               "lmi_nms_v8: bad shape batch=%d nc=%d nm=%d anchors=%d", batch, nc, nm, anchors);
   LMI_REQUIRE(anchors <= (1 << 24), LMI_ERR_LIMIT, "lmi_nms_v8: anchors %d > 2^24", anchors);
@@ -1037,6 +1115,7 @@ static int nms_check(const float *pred, int batch, int nc, int nm, int anchors, 
   C.keys = reinterpret_cast<uint64_t *>(C.ws + C.L.off_keys);
   C.cls_of = reinterpret_cast<int *>(C.ws + C.L.off_cls);
   C.sbox = reinterpret_cast<float4 *>(C.ws + C.L.off_sbox);
+  C.half = pred_dtype == LMI_F16 ? 1 : 0;
   return LMI_OK;
 }
 
@@ -1050,23 +1129,47 @@ static int nms_check_suppress(const float *out_det, const int32_t *out_count, co
   return LMI_OK;
 }
 
+static int fin_check(const lmi_finalize_args *fin, int batch, int rotated) {
+  if (fin == nullptr) return LMI_OK;
+  LMI_REQUIRE(!rotated, LMI_ERR_BAD_ARG, "lmi_nms_v8_ex: the fused finalize serves axis-aligned boxes only (use lmi_finalize_obb)");
+  LMI_REQUIRE(fin->keep && fin->keep_count, LMI_ERR_BAD_ARG, "lmi_nms_v8_ex: finalize: NULL pointer");
+  LMI_REQUIRE(batch <= 8192, LMI_ERR_BAD_ARG, "lmi_nms_v8_ex: finalize: batch %d > 8192", batch);
+  LMI_REQUIRE(fin->model_h > 0 && fin->model_w > 0, LMI_ERR_BAD_ARG, "lmi_nms_v8_ex: finalize: bad model size");
+  LMI_REQUIRE(fin->orig_hw != nullptr || (fin->uniform_h0 > 0 && fin->uniform_w0 > 0), LMI_ERR_BAD_ARG, "lmi_nms_v8_ex: finalize: original image size missing");
+  LMI_REQUIRE(fin->slot_map == nullptr || fin->mask_slot != nullptr, LMI_ERR_BAD_ARG, "lmi_nms_v8_ex: finalize: slot_map needs mask_slot");
+  return LMI_OK;
+}
+
 // first half: candidate filter (HBM-bound, reads the head once)
-static int nms_decode(const NmsCall &C, const float *pred, int batch, int nc, int nm, int anchors, float conf_thres) {
+static int nms_decode(const NmsCall &C, const void *pred, int batch, int nc, int nm, int anchors, float conf_thres) {
   hipError_t e = hipMemsetAsync(C.cand_count, 0, sizeof(int) * (size_t)batch, C.s);
   if (e != hipSuccess) { lmi_set_error("lmi_nms_v8: hipMemsetAsync: %s", hipGetErrorString(e)); return LMI_ERR_LAUNCH; }
+  const float *pf = reinterpret_cast<const float *>(pred);
+  const __half *ph = reinterpret_cast<const __half *>(pred);
   if ((anchors & 3) == 0) {
     dim3 grid((anchors / 4 + 63) / 64, batch);
-    hipLaunchKernelGGL(nms_decode_filter<4>, grid, dim3(256), 0, C.s, pred, nc, nm, anchors, conf_thres, C.keys, C.L.P, C.cls_of, C.cand_count);
+    if (C.half) hipLaunchKernelGGL((nms_decode_filter<4, __half>), grid, dim3(256), 0, C.s, ph, nc, nm, anchors, conf_thres, C.keys, C.L.P, C.cls_of, C.cand_count);
+    else hipLaunchKernelGGL((nms_decode_filter<4, float>), grid, dim3(256), 0, C.s, pf, nc, nm, anchors, conf_thres, C.keys, C.L.P, C.cls_of, C.cand_count);
   } else {
     dim3 grid((anchors + 63) / 64, batch);
-    hipLaunchKernelGGL(nms_decode_filter<1>, grid, dim3(256), 0, C.s, pred, nc, nm, anchors, conf_thres, C.keys, C.L.P, C.cls_of, C.cand_count);
+    if (C.half) hipLaunchKernelGGL((nms_decode_filter<1, __half>), grid, dim3(256), 0, C.s, ph, nc, nm, anchors, conf_thres, C.keys, C.L.P, C.cls_of, C.cand_count);
+    else hipLaunchKernelGGL((nms_decode_filter<1, float>), grid, dim3(256), 0, C.s, pf, nc, nm, anchors, conf_thres, C.keys, C.L.P, C.cls_of, C.cand_count);
   }
   return lmi_check_launch("nms_decode_filter");
 }
 
-// second half: sort + suppression, one workgroup per image (latency / LDS-bound, next to no HBM traffic)
-static int nms_suppress(const NmsCall &C, const float *pred, int batch, int nc, int nm, int anchors, double iou_thres, int agnostic,
-                        int max_det, int max_nms, float max_wh, float *out_det, int32_t *out_count, int32_t *out_anchor, int rotated) {
+static void fin_params(const lmi_finalize_args *fin, float *det, const int32_t *count, int batch, int max_det, int det_stride, int nc,
+                       FinalizeParams &F) {
+  F.det = det; F.count = count; F.batch = batch; F.max_det = max_det; F.det_stride = det_stride; F.nc = nc;
+  F.model_h = fin->model_h; F.model_w = fin->model_w; F.orig_hw = fin->orig_hw; F.uh0 = fin->uniform_h0; F.uw0 = fin->uniform_w0;
+  F.pad_round = fin->pad_round ? 1 : 0; F.thres = fin->thres; F.uniform_thres = fin->uniform_thres; F.keep = fin->keep;
+  F.keep_count = fin->keep_count; F.mask_slot = fin->mask_slot; F.slot_map = fin->slot_map; F.slot_base = fin->slot_base;
+}
+
+// second half: sort + suppression (+ the fused finalize), one workgroup per image (latency / LDS-bound, next to no HBM traffic)
+static int nms_suppress(const NmsCall &C, const void *pred, int batch, int nc, int nm, int anchors, double iou_thres, int agnostic,
+                        int max_det, int max_nms, float max_wh, float *out_det, int32_t *out_count, int32_t *out_anchor, int rotated,
+                        const lmi_finalize_args *fin) {
   // torchvision compares the fp32 IoU against the threshold as a double: use the largest fp32 <= thr.
   // nms_rotated compares `ious.max(0) < threshold` in fp32 (tensor vs Python float): the threshold rounded to fp32.
   float thr = (float)iou_thres;
@@ -1075,7 +1178,7 @@ static int nms_suppress(const NmsCall &C, const float *pred, int batch, int nc, 
   int rc0 = nms_device_state(&D);   // first call on this GPU: LDS limits of the sort kernels
   if (rc0) return rc0;
 
-  SortNmsParams S;
+  SortNmsParams S{};
   S.pred = pred; S.nc = nc; S.nm = nm; S.A = anchors; S.iou_thr = thr; S.agnostic = agnostic ? 1 : 0;
   S.max_det = max_det; S.max_nms = max_nms; S.max_wh = max_wh; S.keys = C.keys; S.P = C.L.P; S.cls_of = C.cls_of;
   S.sbox = C.sbox; S.cand_count = C.cand_count; S.out_det = out_det; S.out_count = out_count; S.out_anchor = out_anchor;
@@ -1085,52 +1188,80 @@ static int nms_suppress(const NmsCall &C, const float *pred, int batch, int nc, 
     LMI_REQUIRE(nm >= 1, LMI_ERR_BAD_ARG, "lmi_nms_v8_rotated: the angle must be the last of nm >= 1 extra channels");
     S.lbox_off = (int)((nms_lds_rot_head(S.lds_keys, max_det) + 15) & ~(size_t)15);
     const size_t lds_rot = (size_t)S.lbox_off + (size_t)S.lds_keys * (16 + 8);
-    hipLaunchKernelGGL(nms_sort_rotated, dim3(batch), dim3(kSortThreads), lds_rot, C.s, S);
+    if (C.half) hipLaunchKernelGGL(nms_sort_rotated<__half>, dim3(batch), dim3(kSortThreads), lds_rot, C.s, S);
+    else hipLaunchKernelGGL(nms_sort_rotated<float>, dim3(batch), dim3(kSortThreads), lds_rot, C.s, S);
     return lmi_check_launch("nms_sort_rotated");
   }
   S.lbox_off = (int)((nms_lds_small(S.lds_keys, max_det) + 15) & ~(size_t)15);
-  const size_t lds = (size_t)S.lbox_off + (size_t)S.lds_keys * 16;
-  hipLaunchKernelGGL(nms_sort_suppress, dim3(batch), dim3(kSortThreads), lds, C.s, S);
-  return lmi_check_launch("nms_sort_suppress");
+  size_t lds = (size_t)S.lbox_off + (size_t)S.lds_keys * 16;
+  if (fin) {
+    S.fin = 1;
+    fin_params(fin, out_det, out_count, batch, max_det, 6 + nm, nc, S.F);
+    if (lds < sizeof(int) * 64) lds = sizeof(int) * 64;   // the epilogue's LDS scratch
+  }
+  if (C.half) hipLaunchKernelGGL(nms_sort_suppress<__half>, dim3(batch), dim3(kSortThreads), lds, C.s, S);
+  else hipLaunchKernelGGL(nms_sort_suppress<float>, dim3(batch), dim3(kSortThreads), lds, C.s, S);
+  int rc = lmi_check_launch("nms_sort_suppress");
+  if (rc || !fin || (fin->mask_slot == nullptr && fin->slot_base == nullptr)) return rc;
+  hipLaunchKernelGGL(finalize_slots_kernel, dim3(batch), dim3(256), 0, C.s, S.F);   // ranks -> dense global mask slots
+  return lmi_check_launch("finalize_slots_kernel");
 }
 
-static int nms_common(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres, double iou_thres,
-                      int agnostic, int max_det, int max_nms, float max_wh, float *out_det, int32_t *out_count,
-                      int32_t *out_anchor, void *workspace, int64_t workspace_bytes, void *stream, int rotated) {
+int lmi_nms_decode_ex(const void *pred, int pred_dtype, int batch, int nc, int nm, int anchors, float conf_thres, void *workspace,
+                      int64_t workspace_bytes, void *stream) {
   NmsCall C;
-  int rc = nms_check(pred, batch, nc, nm, anchors, workspace, workspace_bytes, stream, C);
+  int rc = nms_check(pred, pred_dtype, batch, nc, nm, anchors, workspace, workspace_bytes, stream, C);
+  if (rc) return rc;
+  return nms_decode(C, pred, batch, nc, nm, anchors, conf_thres);
+}
+
+int lmi_nms_suppress_ex(const void *pred, int pred_dtype, int batch, int nc, int nm, int anchors, double iou_thres, int agnostic,
+                        int max_det, int max_nms, float max_wh, int rotated, const lmi_finalize_args *fin, float *out_det,
+                        int32_t *out_count, int32_t *out_anchor, void *workspace, int64_t workspace_bytes, void *stream) {
+  NmsCall C;
+  int rc = nms_check(pred, pred_dtype, batch, nc, nm, anchors, workspace, workspace_bytes, stream, C);
   if (rc) return rc;
   rc = nms_check_suppress(out_det, out_count, out_anchor, iou_thres, max_det, max_nms);
   if (rc) return rc;
+  rc = fin_check(fin, batch, rotated);
+  if (rc) return rc;
+  return nms_suppress(C, pred, batch, nc, nm, anchors, iou_thres, agnostic, max_det, max_nms, max_wh, out_det, out_count, out_anchor,
+                      rotated ? 1 : 0, fin);
+}
+
+int lmi_nms_v8_ex(const void *pred, int pred_dtype, int batch, int nc, int nm, int anchors, float conf_thres, double iou_thres,
+                  int agnostic, int max_det, int max_nms, float max_wh, int rotated, const lmi_finalize_args *fin, float *out_det,
+                  int32_t *out_count, int32_t *out_anchor, void *workspace, int64_t workspace_bytes, void *stream) {
+  NmsCall C;
+  int rc = nms_check(pred, pred_dtype, batch, nc, nm, anchors, workspace, workspace_bytes, stream, C);
+  if (rc) return rc;
+  rc = nms_check_suppress(out_det, out_count, out_anchor, iou_thres, max_det, max_nms);
+  if (rc) return rc;
+  rc = fin_check(fin, batch, rotated);
+  if (rc) return rc;
   rc = nms_decode(C, pred, batch, nc, nm, anchors, conf_thres);
   if (rc) return rc;
-  return nms_suppress(C, pred, batch, nc, nm, anchors, iou_thres, agnostic, max_det, max_nms, max_wh, out_det, out_count, out_anchor, rotated);
+  return nms_suppress(C, pred, batch, nc, nm, anchors, iou_thres, agnostic, max_det, max_nms, max_wh, out_det, out_count, out_anchor,
+                      rotated ? 1 : 0, fin);
 }
 
 int lmi_nms_decode(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres, void *workspace,
                    int64_t workspace_bytes, void *stream) {
-  NmsCall C;
-  int rc = nms_check(pred, batch, nc, nm, anchors, workspace, workspace_bytes, stream, C);
-  if (rc) return rc;
-  return nms_decode(C, pred, batch, nc, nm, anchors, conf_thres);
+  return lmi_nms_decode_ex(pred, LMI_F32, batch, nc, nm, anchors, conf_thres, workspace, workspace_bytes, stream);
 }
 
 int lmi_nms_suppress(const float *pred, int batch, int nc, int nm, int anchors, double iou_thres, int agnostic, int max_det,
                      int max_nms, float max_wh, int rotated, float *out_det, int32_t *out_count, int32_t *out_anchor,
                      void *workspace, int64_t workspace_bytes, void *stream) {
-  NmsCall C;
-  int rc = nms_check(pred, batch, nc, nm, anchors, workspace, workspace_bytes, stream, C);
-  if (rc) return rc;
-  rc = nms_check_suppress(out_det, out_count, out_anchor, iou_thres, max_det, max_nms);
-  if (rc) return rc;
-  return nms_suppress(C, pred, batch, nc, nm, anchors, iou_thres, agnostic, max_det, max_nms, max_wh, out_det, out_count, out_anchor, rotated ? 1 : 0);
+  return lmi_nms_suppress_ex(pred, LMI_F32, batch, nc, nm, anchors, iou_thres, agnostic, max_det, max_nms, max_wh, rotated, nullptr,
+                             out_det, out_count, out_anchor, workspace, workspace_bytes, stream);
 }
 
 int lmi_nms_v8(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres, double iou_thres,
                int agnostic, int max_det, int max_nms, float max_wh, float *out_det, int32_t *out_count,
                int32_t *out_anchor, void *workspace, int64_t workspace_bytes, void *stream) {
-  return nms_common(pred, batch, nc, nm, anchors, conf_thres, iou_thres, agnostic, max_det, max_nms, max_wh, out_det, out_count,
-                    out_anchor, workspace, workspace_bytes, stream, 0);
+  return lmi_nms_v8_ex(pred, LMI_F32, batch, nc, nm, anchors, conf_thres, iou_thres, agnostic, max_det, max_nms, max_wh, 0, nullptr,
+                       out_det, out_count, out_anchor, workspace, workspace_bytes, stream);
 }
 
 int lmi_nms_v8_static(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres, double iou_thres,
@@ -1144,17 +1275,17 @@ int lmi_nms_v8_static(const float *pred, int batch, int nc, int nm, int anchors,
   NmsDeviceState *D = nullptr;
   int rc = nms_device_state(&D);
   if (rc) return rc;
-  // same kernels as lmi_nms_v8, on this GPU's copy of `scratch`; nms_decode clears the candidate counts, every
+  // same kernels as lmi_nms_v8, on this GPU's copy of `scratch`; the decode half clears the candidate counts, every
   // other part of the workspace is written before it is read
-  return nms_common(pred, batch, nc, nm, anchors, conf_thres, iou_thres, agnostic, max_det, max_nms, max_wh, out_det, out_count,
-                    out_anchor, D->scratch_ptr, (int64_t)LMI_NMS_STATIC_BYTES, stream, 0);
+  return lmi_nms_v8_ex(pred, LMI_F32, batch, nc, nm, anchors, conf_thres, iou_thres, agnostic, max_det, max_nms, max_wh, 0, nullptr,
+                       out_det, out_count, out_anchor, D->scratch_ptr, (int64_t)LMI_NMS_STATIC_BYTES, stream);
 }
 
 int lmi_nms_v8_rotated(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres, double iou_thres,
                        int agnostic, int max_det, int max_nms, float max_wh, float *out_det, int32_t *out_count,
                        int32_t *out_anchor, void *workspace, int64_t workspace_bytes, void *stream) {
-  return nms_common(pred, batch, nc, nm, anchors, conf_thres, iou_thres, agnostic, max_det, max_nms, max_wh, out_det, out_count,
-                    out_anchor, workspace, workspace_bytes, stream, 1);
+  return lmi_nms_v8_ex(pred, LMI_F32, batch, nc, nm, anchors, conf_thres, iou_thres, agnostic, max_det, max_nms, max_wh, 1, nullptr,
+                       out_det, out_count, out_anchor, workspace, workspace_bytes, stream);
 }
 
 int lmi_finalize_detections(float *det, const int32_t *count, int batch, int max_det, int det_stride, int nc, int model_h,

@@ -36,8 +36,9 @@ class _WorkspaceCache:
 _ws = _WorkspaceCache()
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device=None) -> int:
+    """The current torch stream of `device` (the tensors' device, not whatever device happens to be current)."""
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def _need_cuda(t: torch.Tensor, name: str) -> None:
@@ -68,7 +69,7 @@ def preprocess_u8(im: torch.Tensor, fp16: bool = False) -> torch.Tensor:
         im = im.contiguous()
     tdt, ldt = _dt(fp16)
     out = torch.empty((1, 3, h, w), dtype=tdt, device=im.device)
-    check(_L.lmi_preprocess_u8(im.data_ptr(), h, w, c, im.stride(0), out.data_ptr(), ldt, _stream()))
+    check(_L.lmi_preprocess_u8(im.data_ptr(), h, w, c, im.stride(0), out.data_ptr(), ldt, _stream(im.device)))
     return out
 
 
@@ -138,7 +139,7 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
         ws = _ws.get(frames.device, "letterbox", int(_L.lmi_letterbox_workspace_bytes(1, dst_h, dst_w)))
         check(_L.lmi_letterbox_u8_uniform(frames.data_ptr(), b, h, w, frames.stride(1), frames.stride(0), out.data_ptr(),
                                           dst_h, dst_w, ldt, pad_value, int(swap_rb), int(stretch), 0, ws.data_ptr(),
-                                          ws.numel(), _stream()))
+                                          ws.numel(), _stream(frames.device)))
         g = letterbox_geometry(h, w, dst_h, dst_w, stretch)
         ops = [[{"resize": [g[0], g[1], w, h]}, {"pad": [g[2], g[3], g[4], g[5]]}] for _ in range(b)]
         return out, ops
@@ -171,54 +172,113 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
         out = torch.empty((len(keep), 3, dst_h, dst_w), dtype=tdt, device=dev)
     ws = _ws.get(dev, "letterbox", int(_L.lmi_letterbox_workspace_bytes(len(keep), dst_h, dst_w)))
     check(_L.lmi_letterbox_u8(C.addressof(desc), ddev.data_ptr(), len(keep), out.data_ptr(), dst_h, dst_w, ldt,
-                              pad_value, int(swap_rb), (2 if torch_threads == 1 else 1) if mode == "torch" else 0, ws.data_ptr(), ws.numel(), _stream()))
-    ddev.record_stream(torch.cuda.current_stream())
+                              pad_value, int(swap_rb), (2 if torch_threads == 1 else 1) if mode == "torch" else 0, ws.data_ptr(), ws.numel(), _stream(dev)))
+    ddev.record_stream(torch.cuda.current_stream(dev))
     return out, ops
+
+
+def _finalize_setup(b: int, max_det: int, nc: int, dev, model_hw, orig_hw, thres, pad_round: bool, with_slots: bool, out):
+    """Buffers + the lmi_finalize_args record shared by finalize_detections and the fused nms_v8(finalize=...).
+    Returns (result dict, args struct, tensors to keep alive until the call is enqueued)."""
+    if out is not None:   # reuse a previous result dict of the same shapes
+        keep, keep_count = out["keep"], out["keep_count"]
+        mask_slot, slot_map, slot_base = out["mask_slot"], out["slot_map"], out["slot_base"]
+        if keep.shape != (b, max_det) or keep.dtype != torch.uint8 or keep.device != dev or not keep.is_contiguous():
+            raise ValueError("finalize: `out` buffers do not match this call's shapes")
+    else:
+        keep = torch.empty((b, max_det), dtype=torch.uint8, device=dev)
+        keep_count = torch.empty((b,), dtype=torch.int32, device=dev)
+        mask_slot = torch.empty((b, max_det), dtype=torch.int32, device=dev) if with_slots else None
+        slot_map = torch.empty((b * max_det,), dtype=torch.int32, device=dev) if with_slots else None
+        slot_base = torch.empty((b + 1,), dtype=torch.int32, device=dev) if with_slots else None
+    alive = []
+    if isinstance(orig_hw, torch.Tensor):
+        _need_cuda(orig_hw, "orig_hw")
+        ohw = orig_hw.to(torch.int32).contiguous()
+        if ohw.shape != (b, 2):
+            raise ValueError("orig_hw must be (B,2)")
+        alive.append(ohw)
+        ohw_ptr, uh, uw = ohw.data_ptr(), 0, 0
+    else:
+        ohw_ptr, uh, uw = None, int(orig_hw[0]), int(orig_hw[1])
+    if isinstance(thres, torch.Tensor):
+        _need_cuda(thres, "thres")
+        th = thres.to(torch.float64).contiguous()
+        if th.numel() != nc:
+            raise ValueError("per-class thresholds must have nc entries")
+        alive.append(th)
+        th_ptr, ut = th.data_ptr(), 0.0
+    else:
+        th_ptr, ut = None, float(thres)
+    p = lambda t: t.data_ptr() if t is not None else None
+    args = _lib.lmi_finalize_args(int(model_hw[0]), int(model_hw[1]), uh, uw, ohw_ptr, int(bool(pad_round)), 0, th_ptr, ut,
+                                  keep.data_ptr(), keep_count.data_ptr(), p(mask_slot), p(slot_map), p(slot_base))
+    res = {"keep": keep, "keep_count": keep_count, "mask_slot": mask_slot, "slot_map": slot_map, "slot_base": slot_base}
+    return res, args, alive
 
 
 def nms_v8(pred: torch.Tensor, conf_thres: float, iou_thres: float = 0.45, agnostic: bool = False, max_det: int = 300,
            nc: int = 0, max_nms: int = 30000, max_wh: float = 7680.0, out=None, rotated: bool = False,
-           decode_done: Optional[torch.cuda.Event] = None):
-    """`ops.non_max_suppression` on the head output (B, 4+nc+nm, A) fp32.  rotated=True: oriented boxes
-    (xywh + angle as the last extra channel, ultralytics' nms_rotated on probiou), rows stay xywh.
+           decode_done: Optional[torch.cuda.Event] = None, finalize: Optional[dict] = None):
+    """`ops.non_max_suppression` on the head output (B, 4+nc+nm, A), fp32 or fp16 (an fp16 head is read as it is,
+    every value promoted to fp32 in the kernels: the result of `pred.float()` without that pass).  rotated=True:
+    oriented boxes (xywh + angle as the last extra channel, ultralytics' nms_rotated on probiou), rows stay xywh.
     decode_done: an event recorded on the current stream between the candidate filter (HBM-bound) and the
     sort + suppression pass (latency-bound): work on another stream that waits for it shares the chip with the
-    latter (lmi_nms_decode / lmi_nms_suppress instead of the one-call lmi_nms_v8; same result).
+    latter (lmi_nms_decode_ex / lmi_nms_suppress_ex instead of the one-call lmi_nms_v8_ex; same result).
+    finalize: dict(model_hw=, orig_hw=, thres=[, pad_round=True, with_slots=True, out=None]) -- the arguments of
+    finalize_detections: scale_boxes + clip, class threshold and survivor ranks then run in the suppression kernel's
+    epilogue (one launch less, same results) and the call returns a 4th value, finalize_detections' result dict.
 
     Returns (det (B,max_det,6+nm) fp32, count (B,) int32, anchor (B,max_det) int32), all on the
     device; rows >= count[b] are unspecified.  `out` = a previous result tuple of the same shapes
     to write into instead of allocating (serving loops)."""
     _need_cuda(pred, "pred")
-    if pred.dtype != torch.float32:
+    if pred.dtype not in (torch.float32, torch.float16):
         pred = pred.float()
     if not pred.is_contiguous():
         pred = pred.contiguous()
+    pdt = LMI_F16 if pred.dtype == torch.float16 else LMI_F32
     b, ch, a = pred.shape
     nc = nc or (ch - 4)
     nm = ch - nc - 4
     if nm < 0:
         raise ValueError(f"nc={nc} does not fit a head with {ch} channels")
+    dev = pred.device
     if out is not None:
         det, count, anchor = out
         if det.shape != (b, max_det, 6 + nm) or count.shape != (b,) or anchor.shape != (b, max_det):
             raise ValueError("nms_v8: `out` buffers do not match this call's shapes")
+        if det.dtype != torch.float32 or count.dtype != torch.int32 or anchor.dtype != torch.int32:
+            raise ValueError("nms_v8: `out` buffers must be (float32, int32, int32)")
+        if not (det.is_contiguous() and count.is_contiguous() and anchor.is_contiguous()) or det.device != dev:
+            raise ValueError("nms_v8: `out` buffers must be contiguous and on the head's device")
     else:
-        det = torch.empty((b, max_det, 6 + nm), dtype=torch.float32, device=pred.device)
-        count = torch.empty((b,), dtype=torch.int32, device=pred.device)
-        anchor = torch.empty((b, max_det), dtype=torch.int32, device=pred.device)
+        det = torch.empty((b, max_det, 6 + nm), dtype=torch.float32, device=dev)
+        count = torch.empty((b,), dtype=torch.int32, device=dev)
+        anchor = torch.empty((b, max_det), dtype=torch.int32, device=dev)
+    fin_res, fin_ptr, alive = None, None, None
+    if finalize is not None:
+        if rotated:
+            raise ValueError("nms_v8: finalize= serves axis-aligned boxes (use finalize_obb for rotated ones)")
+        fin_res, fin_args, alive = _finalize_setup(b, max_det, nc, dev, finalize["model_hw"], finalize["orig_hw"], finalize["thres"],
+                                                   finalize.get("pad_round", True), finalize.get("with_slots", True), finalize.get("out"))
+        fin_ptr = C.addressof(fin_args)
     nbytes = int(_L.lmi_nms_workspace_bytes(b, a))
-    ws = _ws.get(pred.device, "nms", nbytes)
+    ws = _ws.get(dev, "nms", nbytes)
+    st = _stream(dev)
     if decode_done is not None:
-        check(_L.lmi_nms_decode(pred.data_ptr(), b, nc, nm, a, float(conf_thres), ws.data_ptr(), ws.numel(), _stream()))
+        check(_L.lmi_nms_decode_ex(pred.data_ptr(), pdt, b, nc, nm, a, float(conf_thres), ws.data_ptr(), ws.numel(), st))
         decode_done.record()
-        check(_L.lmi_nms_suppress(pred.data_ptr(), b, nc, nm, a, float(iou_thres), int(agnostic), int(max_det), int(max_nms),
-                                  float(max_wh), int(rotated), det.data_ptr(), count.data_ptr(), anchor.data_ptr(), ws.data_ptr(),
-                                  ws.numel(), _stream()))
-        return det, count, anchor
-    fn = _L.lmi_nms_v8_rotated if rotated else _L.lmi_nms_v8
-    check(fn(pred.data_ptr(), b, nc, nm, a, float(conf_thres), float(iou_thres), int(agnostic), int(max_det),
-             int(max_nms), float(max_wh), det.data_ptr(), count.data_ptr(), anchor.data_ptr(), ws.data_ptr(),
-             ws.numel(), _stream()))
+        check(_L.lmi_nms_suppress_ex(pred.data_ptr(), pdt, b, nc, nm, a, float(iou_thres), int(agnostic), int(max_det), int(max_nms),
+                                     float(max_wh), int(rotated), fin_ptr, det.data_ptr(), count.data_ptr(), anchor.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), st))
+    else:
+        check(_L.lmi_nms_v8_ex(pred.data_ptr(), pdt, b, nc, nm, a, float(conf_thres), float(iou_thres), int(agnostic), int(max_det),
+                               int(max_nms), float(max_wh), int(rotated), fin_ptr, det.data_ptr(), count.data_ptr(), anchor.data_ptr(),
+                               ws.data_ptr(), ws.numel(), st))
+    if finalize is not None:
+        return det, count, anchor, fin_res
     return det, count, anchor
 
 
@@ -247,7 +307,7 @@ def finalize_obb(det: torch.Tensor, count: torch.Tensor, nc: int, model_hw: Tupl
     else:
         th_ptr, ut = None, float(thres)
     check(_L.lmi_finalize_obb(det.data_ptr(), count.data_ptr(), b, max_det, stride, nc, int(model_hw[0]), int(model_hw[1]),
-                              ohw_ptr, uh, uw, th_ptr, ut, corners.data_ptr(), keep.data_ptr(), keep_count.data_ptr(), _stream()))
+                              ohw_ptr, uh, uw, th_ptr, ut, corners.data_ptr(), keep.data_ptr(), keep_count.data_ptr(), _stream(det.device)))
     return {"corners": corners, "keep": keep, "keep_count": keep_count}
 
 
@@ -260,38 +320,14 @@ def finalize_detections(det: torch.Tensor, count: torch.Tensor, nc: int, model_h
     float64 device tensor (nc,) of per-class thresholds.
     Returns dict(keep (B,max_det) uint8, keep_count (B,), mask_slot, slot_map, slot_base (B+1,))."""
     _need_cuda(det, "det")
+    if det.dtype != torch.float32 or not det.is_contiguous() or det.ndim != 3:
+        raise ValueError("finalize_detections: det must be a contiguous float32 (B,max_det,6+nm) tensor")
     b, max_det, stride = det.shape
-    dev = det.device
-    if out is not None:   # reuse a previous result dict of the same shapes
-        keep, keep_count = out["keep"], out["keep_count"]
-        mask_slot, slot_map, slot_base = out["mask_slot"], out["slot_map"], out["slot_base"]
-        if keep.shape != (b, max_det):
-            raise ValueError("finalize_detections: `out` buffers do not match this call's shapes")
-    else:
-        keep = torch.empty((b, max_det), dtype=torch.uint8, device=dev)
-        keep_count = torch.empty((b,), dtype=torch.int32, device=dev)
-        mask_slot = torch.empty((b, max_det), dtype=torch.int32, device=dev) if with_slots else None
-        slot_map = torch.empty((b * max_det,), dtype=torch.int32, device=dev) if with_slots else None
-        slot_base = torch.empty((b + 1,), dtype=torch.int32, device=dev) if with_slots else None
-    if isinstance(orig_hw, torch.Tensor):
-        _need_cuda(orig_hw, "orig_hw")
-        ohw = orig_hw.to(torch.int32).contiguous()
-        ohw_ptr, uh, uw = ohw.data_ptr(), 0, 0
-    else:
-        ohw, ohw_ptr, uh, uw = None, None, int(orig_hw[0]), int(orig_hw[1])
-    if isinstance(thres, torch.Tensor):
-        _need_cuda(thres, "thres")
-        th = thres.to(torch.float64).contiguous()
-        if th.numel() != nc:
-            raise ValueError("per-class thresholds must have nc entries")
-        th_ptr, ut = th.data_ptr(), 0.0
-    else:
-        th, th_ptr, ut = None, None, float(thres)
-    p = lambda t: t.data_ptr() if t is not None else None
-    check(_L.lmi_finalize_detections(det.data_ptr(), count.data_ptr(), b, max_det, stride, nc, int(model_hw[0]),
-                                     int(model_hw[1]), ohw_ptr, uh, uw, int(pad_round), th_ptr, ut, keep.data_ptr(),
-                                     keep_count.data_ptr(), p(mask_slot), p(slot_map), p(slot_base), _stream()))
-    return {"keep": keep, "keep_count": keep_count, "mask_slot": mask_slot, "slot_map": slot_map, "slot_base": slot_base}
+    res, a, alive = _finalize_setup(b, max_det, nc, det.device, model_hw, orig_hw, thres, pad_round, with_slots, out)
+    check(_L.lmi_finalize_detections(det.data_ptr(), count.data_ptr(), b, max_det, stride, nc, a.model_h, a.model_w, a.orig_hw,
+                                     a.uniform_h0, a.uniform_w0, a.pad_round, a.thres, a.uniform_thres, a.keep, a.keep_count,
+                                     a.mask_slot, a.slot_map, a.slot_base, _stream(det.device)))
+    return res
 
 
 def scale_coords(det: torch.Tensor, count: torch.Tensor, nkpt: int, ndim: int, model_hw: Tuple[int, int],
@@ -306,7 +342,7 @@ def scale_coords(det: torch.Tensor, count: torch.Tensor, nkpt: int, ndim: int, m
     else:
         ohw_ptr, uh, uw = None, int(orig_hw[0]), int(orig_hw[1])
     check(_L.lmi_scale_coords(det.data_ptr(), count.data_ptr(), b, max_det, stride, int(col0), int(nkpt), int(ndim),
-                              int(model_hw[0]), int(model_hw[1]), ohw_ptr, uh, uw, _stream()))
+                              int(model_hw[0]), int(model_hw[1]), ohw_ptr, uh, uw, _stream(det.device)))
     return det
 
 
@@ -346,16 +382,16 @@ def process_mask(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.Tensor,
     if split_events is None and before_upsample is None:
         check(_L.lmi_process_mask(proto.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
                                   slot_base.data_ptr(), h0, w0, out.data_ptr(), ldt, capacity, overflow.data_ptr(),
-                                  ws.data_ptr(), ws.numel(), _stream()))
+                                  ws.data_ptr(), ws.numel(), _stream(proto.device)))
     else:
         check(_L.lmi_mask_logits(proto.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
-                                 slot_base.data_ptr(), h0, w0, capacity, ws.data_ptr(), ws.numel(), _stream()))
+                                 slot_base.data_ptr(), h0, w0, capacity, ws.data_ptr(), ws.numel(), _stream(proto.device)))
         if before_upsample is not None:
             before_upsample()
         if split_events is not None:
             split_events[0].record()
         check(_L.lmi_mask_upsample(ws.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
-                                   slot_base.data_ptr(), h0, w0, out.data_ptr(), ldt, capacity, overflow.data_ptr(), _stream()))
+                                   slot_base.data_ptr(), h0, w0, out.data_ptr(), ldt, capacity, overflow.data_ptr(), _stream(proto.device)))
         if split_events is not None:
             split_events[1].record()
     return out, overflow
@@ -398,7 +434,7 @@ def revert_points(pts: torch.Tensor, operations: Sequence[dict]) -> torch.Tensor
     src = pts.contiguous()
     out = torch.empty_like(src)
     arr, n = point_ops(operations)
-    check(_L.lmi_revert_points_f32(src.data_ptr(), src.numel() // 2, C.cast(arr, C.c_void_p), n, out.data_ptr(), _stream()))
+    check(_L.lmi_revert_points_f32(src.data_ptr(), src.numel() // 2, C.cast(arr, C.c_void_p), n, out.data_ptr(), _stream(src.device)))
     return out
 
 
@@ -459,7 +495,7 @@ def revert_masks(masks: torch.Tensor, operations: Sequence[dict]) -> torch.Tenso
     for fit_h, fit_w, rs_h, rs_w, lr, ud, oh, ow in mask_stages(cur.shape[1], cur.shape[2], operations):
         out = torch.empty((m, oh, ow), dtype=cur.dtype, device=cur.device)
         check(_L.lmi_revert_masks_stage(cur.data_ptr(), ldt, m, cur.shape[1], cur.shape[2], fit_h, fit_w, rs_h, rs_w,
-                                        1 if lr else 0, 1 if ud else 0, out.data_ptr(), _stream()))
+                                        1 if lr else 0, 1 if ud else 0, out.data_ptr(), _stream(cur.device)))
         cur = out
     return cur
 
@@ -483,5 +519,5 @@ def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, image_shape: Tuple[int
     m = masks.float().contiguous()
     b = boxes.float().contiguous()
     check(_L.lmi_paste_masks(m.data_ptr(), n, m.shape[1], m.shape[2], b.data_ptr(), b.shape[1], h, w, float(threshold),
-                             out.data_ptr(), _stream()))
+                             out.data_ptr(), _stream(m.device)))
     return out.view(torch.bool)

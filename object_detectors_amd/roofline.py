@@ -39,6 +39,37 @@ def mask_upsample_bytes(n_masks: int, h0: int, w0: int, mh: int, mw: int, out_el
     return n_masks * (h0 * w0 * out_elem + wh * ww * 4)
 
 
+def _aten_src_index(scale: float, d: int, in_n: int):
+    """(i0, i1) of aten's bilinear source index for output index d (align_corners=False), fp32 like the kernels."""
+    import numpy as np
+    s = max(np.float32(scale) * (np.float32(d) + np.float32(0.5)) - np.float32(0.5), np.float32(0))
+    i0 = int(s)
+    return i0, i0 + (1 if i0 < in_n - 1 else 0)
+
+
+def mask_upsample_bytes_exact(boxes, h0: int, w0: int, mh: int, mw: int, out_elem: int = 1) -> int:
+    """Per launch, from the survivors' boxes (n,4) in original-image pixels: every full-resolution mask written once
+    + the logits rows x columns that the pixels under each box read (what the box pass fetches; the logits outside a
+    box are neither computed nor read).  Round 1 charged the whole crop window per survivor, which over-counts."""
+    import math
+    import numpy as np
+    wh, ww = mask_crop_rows(mh, mw, h0, w0)
+    sh, sw = np.float32(wh) / np.float32(h0), np.float32(ww) / np.float32(w0)
+    total = 0
+    for x1, y1, x2, y2 in np.asarray(boxes, dtype=np.float64):
+        total += h0 * w0 * out_elem
+        if not (x1 < x2 and y1 < y2):
+            continue
+        xa, xb = max(0, math.ceil(x1)), min(w0, math.ceil(x2))
+        ya, yb = max(0, math.ceil(y1)), min(h0, math.ceil(y2))
+        if xa >= xb or ya >= yb:
+            continue
+        r0, r1 = _aten_src_index(sh, ya, wh)[0], _aten_src_index(sh, yb - 1, wh)[1]
+        c0, c1 = _aten_src_index(sw, xa, ww)[0], _aten_src_index(sw, xb - 1, ww)[1]
+        total += (r1 - r0 + 1) * (c1 - c0 + 1) * 4
+    return int(total)
+
+
 def mask_logits_bytes(batch: int, n_masks: int, h0: int, w0: int, mh: int, mw: int, nm: int = 32) -> int:
     """Per launch: the crop-window rows of every prototype read once + logits written once + coefficients."""
     wh, _ = mask_crop_rows(mh, mw, h0, w0)

@@ -46,3 +46,16 @@ def gather_report(local: Dict[str, float], device=None) -> List[Dict[str, float]
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [dict(zip(keys, o.tolist())) for o in out]
+
+
+def gather_vector(local: torch.Tensor, device=None) -> List[torch.Tensor]:
+    """all_gather of a 1-D float64 tensor of equal length on every rank (e.g. per-block timings); returns the list of
+    per-rank CPU tensors.  Without an initialised process group it returns [local]."""
+    import torch.distributed as dist
+    local = local.to(torch.float64).flatten()
+    if not (dist.is_available() and dist.is_initialized()):
+        return [local.cpu()]
+    t = local.to(device) if device is not None else local
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.cpu() for o in out]
