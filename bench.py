@@ -86,6 +86,7 @@ class Pipeline:
         self.fin_out = None
         self.side = torch.cuda.Stream(device=dev)
         self.decode_done = torch.cuda.Event()
+        self.logits = "rows"
 
     def size_masks(self):
         """Survivor count of every batch of the pool (one eager pass each, host sync) -> one mask buffer that holds any."""
@@ -146,7 +147,7 @@ class Pipeline:
                                           # the side stream joins BEFORE the upsample: nothing may run beside the zero fill of
                                           # the masks, whose write pattern collapses under concurrent traffic
                                           # (profiles/r01/write_ceiling.md)
-                                          before_upsample=join)
+                                          before_upsample=join, logits=self.logits)
         return det, count, anchor, fin, masks
 
 
@@ -197,6 +198,9 @@ def main():
                     "event-timed pass right after the timed region)")
     ap.add_argument("--graph", action="store_true", help=argparse.SUPPRESS)   # the default since r01; kept for old command lines
     ap.add_argument("--no-fork", action="store_true", help="run the letterbox and the NMS chain on one stream (measurement)")
+    ap.add_argument("--mask-logits", default="rows", choices=["rows", "mfma"],
+                    help="coefficient x prototype product: row-sparse vector-ALU kernel (default) or dense fp32 MFMA tiles "
+                         "(measurement of the MFMA variant; the LMI_MASK_LOGITS_MFMA flag of lmi_process_mask_ex)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -227,6 +231,7 @@ def main():
     pool = [make_inputs(cfg, args.seed + 1000 * rank + 7919 * i, device) for i in range(max(args.pool, 1))]
     frames, head, proto = pool[0]
     pipe = Pipeline(cfg, pool)
+    pipe.logits = args.mask_logits
     pipe.size_masks()
     fork = not args.no_fork
     log(f"[bench r{rank}] inputs ready in {time.perf_counter() - t_gen:.1f}s: {cfg['desc']} (pool of {len(pool)} batches)")
@@ -371,7 +376,7 @@ def main():
                        "total_images": args.images if args.images > 0 else None,
                        "per_rank": [{"images": int(r["images"]), "survivors": int(r["survivors"]), "kept_checksum": (int(r["chk_hi"]) << 31) | int(r["chk_lo"])} for r in reports],
                        "mask_dtype": "uint8", "forward": "excluded", "launch": "hip graph replay" if graphs is not None else "eager",
-                       "streams": "letterbox forked beside NMS sort+suppress+finalize" if fork else "one",
+                       "streams": "letterbox forked beside NMS sort+suppress+finalize" if fork else "one", "mask_logits": args.mask_logits,
                        "sharding": f"{world} x independent batches, no collective on the hot path"},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -293,12 +293,44 @@ int lmi_scale_coords(float *det, const int32_t *count, int batch, int max_det, i
  *   capacity_masks  number of mask planes out_masks can hold; slots beyond it are skipped and
  *              their number is written to overflow[0] ([device] int32, may be NULL)
  *   workspace  [device] >= lmi_mask_workspace_bytes(capacity_masks, mh, mw), 256-byte aligned
- * Only uniform originals (every image H0 x W0) are supported by this entry.
+ * These three entries serve uniform originals (every image H0 x W0); the _ex forms above take a table of sizes.
  * lmi_process_mask = lmi_mask_logits (the coefficient x prototype product, and one box record per slot, into
  * `workspace`) followed by lmi_mask_upsample (crop + bilinear + box crop + threshold from the `workspace`
  * lmi_mask_logits left, same arguments); the two halves are exported so a caller can time or schedule
  * them separately.
  */
+/* General forms ("_ex") of the three calls below: same reference lines, plus
+ *   images_host / images_dev  NULL, or one lmi_mask_image per image, the same array in host memory (validated, used to
+ *               size the launch) and in device memory (read by the kernels): a batch of DIFFERENTLY sized originals
+ *               -- `Yolov8.postprocess` takes a list of them, object_detectors/yolov8_lmi/model.py:215-236 -- in one
+ *               launch.  h0 / w0 are then ignored; the masks of image b are written back to back from element
+ *               out_offset (h0*w0 elements each, score order), wherever the caller laid them out in out_masks
+ *               (out_elems = elements out_masks holds).  The caller knows the survivor counts at that point (it
+ *               sized the buffer from them): n_masks must equal slot_base[b+1] - slot_base[b].
+ *   flags       LMI_MASK_LOGITS_MFMA: the coefficient x prototype product as dense fp32 MFMA tiles for every shape;
+ *               LMI_MASK_UPSAMPLE_SINGLE: the one-pass upsample kernel for every shape (both: measurement)
+ */
+typedef struct lmi_mask_image {
+  int32_t h0, w0;      /* original frame size of this image */
+  int32_t n_masks;     /* survivors of this image */
+  int32_t reserved;
+  int64_t out_offset;  /* element offset of the image's first mask in out_masks */
+} lmi_mask_image;
+enum lmi_mask_flags { LMI_MASK_LOGITS_MFMA = 1, LMI_MASK_UPSAMPLE_SINGLE = 2 };
+int lmi_mask_logits_ex(const float *proto, int batch, int nm, int mh, int mw, const float *det, int max_det,
+                       int det_stride, const int32_t *slot_map, const int32_t *slot_base, int h0, int w0,
+                       const lmi_mask_image *images_host, const lmi_mask_image *images_dev,
+                       int64_t capacity_masks, void *workspace, int64_t workspace_bytes, int flags, void *stream);
+int lmi_mask_upsample_ex(void *workspace, int batch, int nm, int mh, int mw, const float *det, int max_det,
+                         int det_stride, const int32_t *slot_map, const int32_t *slot_base, int h0, int w0,
+                         const lmi_mask_image *images_host, const lmi_mask_image *images_dev, void *out_masks,
+                         int out_dtype, int64_t capacity_masks, int64_t out_elems, int32_t *overflow, int flags,
+                         void *stream);
+int lmi_process_mask_ex(const float *proto, int batch, int nm, int mh, int mw, const float *det, int max_det,
+                        int det_stride, const int32_t *slot_map, const int32_t *slot_base, int h0, int w0,
+                        const lmi_mask_image *images_host, const lmi_mask_image *images_dev, void *out_masks,
+                        int out_dtype, int64_t capacity_masks, int64_t out_elems, int32_t *overflow,
+                        void *workspace, int64_t workspace_bytes, int flags, void *stream);
 int64_t lmi_mask_workspace_bytes(int64_t capacity_masks, int mh, int mw);
 int lmi_mask_logits(const float *proto, int batch, int nm, int mh, int mw, const float *det,
                     int max_det, int det_stride, const int32_t *slot_map, const int32_t *slot_base,

@@ -34,6 +34,13 @@ class lmi_finalize_args(C.Structure):
                 ("slot_map", C.c_void_p), ("slot_base", C.c_void_p)]
 
 
+class lmi_mask_image(C.Structure):
+    _fields_ = [("h0", C.c_int32), ("w0", C.c_int32), ("n_masks", C.c_int32), ("reserved", C.c_int32), ("out_offset", C.c_int64)]
+
+
+LMI_MASK_LOGITS_MFMA, LMI_MASK_UPSAMPLE_SINGLE = 1, 2
+
+
 class lmi_point_op(C.Structure):
     _fields_ = [("kind", C.c_int32), ("x", C.c_float), ("y", C.c_float)]
 
@@ -81,6 +88,15 @@ SIGNATURES = {
                                    C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lmi_scale_coords": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "lmi_mask_logits_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
+                                     C.c_void_p]),
+    "lmi_mask_upsample_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64,
+                                       C.c_void_p, C.c_int, C.c_void_p]),
+    "lmi_process_mask_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "lmi_mask_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "lmi_mask_logits": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),

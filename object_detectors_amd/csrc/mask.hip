@@ -18,10 +18,11 @@
 //  mask_box_kernel       the chunks that meet a box: bilinear (align_corners=False) -> box crop -> `> 0`
 //                        from logits rows staged in LDS, 16 bytes per lane per store.
 //  mask_upsample_kernel  the same result in one pass (per survivor, per strip of output rows, zeros included),
-//                        for row lengths that are not whole chunks; `LMI_MASK_UPSAMPLE=single` selects it for
-//                        every shape (measurement).
-#include <cstdlib>
-#include <cstring>
+//                        for row lengths that are not whole chunks and for tiny frames (h0 + w0 <= 128, where aten
+//                        interpolates with its 4-weight kernel); LMI_MASK_UPSAMPLE_SINGLE selects it for every shape.
+// Every kernel takes the geometry per image (MaskBatch): a batch of differently sized originals
+// (object_detectors/yolov8_lmi/model.py:215-236 loops over them) is one launch, masks packed back to back.
+#include <mutex>
 
 #include "common.h"
 
@@ -35,6 +36,36 @@ struct MaskGeom {
   int h0, w0;                    // original frame size
 };
 
+// ultralytics scale_masks: gain = min(mh/h0, mw/w0); pad = (mw - w0*gain)/2, (mh - h0*gain)/2;
+// top,left = int(pad_y), int(pad_x); bottom,right = int(mh - pad_y), int(mw - pad_x)   (Python floats: fp64)
+__host__ __device__ inline void crop_window(int mh, int mw, int h0, int w0, MaskGeom &g) {
+  const double gh = (double)mh / (double)h0, gw = (double)mw / (double)w0;
+  const double gain = gh < gw ? gh : gw;
+  const double pad_x = ((double)mw - (double)w0 * gain) / 2.0;
+  const double pad_y = ((double)mh - (double)h0 * gain) / 2.0;
+  g.mh = mh; g.mw = mw; g.h0 = h0; g.w0 = w0;
+  g.top = (int)pad_y; g.left = (int)pad_x;
+  g.bottom = (int)((double)mh - pad_y); g.right = (int)((double)mw - pad_x);
+}
+
+// The batch's originals: one size for all (images == nullptr; the geometry comes ready from the host), or a device
+// table with one record per image.
+struct MaskBatch {
+  const lmi_mask_image *images;
+  MaskGeom g;
+};
+__device__ __forceinline__ MaskGeom image_geom(const MaskBatch &M, int b) {
+  if (M.images == nullptr) return M.g;
+  MaskGeom g;
+  crop_window(M.g.mh, M.g.mw, M.images[b].h0, M.images[b].w0, g);
+  return g;
+}
+// element offset of a slot's mask in the output: slot * H0 * W0, or behind the image's first mask
+__device__ __forceinline__ long long mask_offset(const MaskBatch &M, const MaskGeom &g, int b, long long slot, int slot_base_b) {
+  if (M.images == nullptr) return slot * (long long)g.h0 * g.w0;
+  return (long long)M.images[b].out_offset + (slot - slot_base_b) * (long long)g.h0 * g.w0;
+}
+
 struct GemmParams {
   const float *proto;  // (batch, 32, mh, mw)
   const float *det;    // (batch, max_det, det_stride)
@@ -43,18 +74,22 @@ struct GemmParams {
   float *logits;  // (capacity, wh*mw)
   int batch, max_det, det_stride;
   long long capacity;
-  MaskGeom g;
+  MaskBatch M;
+  int lstride;          // floats per slot in `logits` (mh * mw)
   int tiles_per_block;  // pixel tiles (32*V px) per wave
   int4 *table;          // per-slot pixel ranges of the box {xa, xb, ya, yb} for mask_box_kernel
 };
 
-// aten upsample_bilinear2d, align_corners=False: source index / weights of output index d
+// aten upsample_bilinear2d, align_corners=False, as torch's x86 CPU build computes it (oracle/geometry.py; the same
+// forms as revert.hip): the source coordinate is ONE fused multiply-add, and each pair of taps is combined as
+// fma(a, wa, b * wb), horizontal pairs first (aten's separable kernel) -- only these reproduce F.interpolate bit for
+// bit.  Outputs with h0 + w0 <= 128 take aten's per-pixel 4-weight kernel (mask_upsample_kernel only).
 __device__ __forceinline__ void bilinear_src(float scale, int d, int in_n, int &i0, int &i1, float &l0, float &l1) {
-  float s = scale * ((float)d + 0.5f) - 0.5f;
+  float s = fmaf(scale, (float)d + 0.5f, -0.5f);
   s = fmaxf(s, 0.0f);
-  i0 = (int)s;
+  i0 = min((int)s, in_n - 1);
   i1 = i0 + ((i0 < in_n - 1) ? 1 : 0);
-  l1 = s - (float)i0;
+  l1 = fminf(fmaxf(s - (float)i0, 0.0f), 1.0f);
   l0 = 1.0f - l1;
 }
 
@@ -77,7 +112,8 @@ __global__ __launch_bounds__(256) void mask_gemm_kernel(GemmParams G) {
   const int row0 = blockIdx.y * 32;
   if (row0 >= m_b) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wh = G.g.bottom - G.g.top;
+  const MaskGeom g = image_geom(G.M, b);
+  const int wh = g.bottom - g.top;
 
   // Logits rows each survivor's upsample will read: the bilinear taps of the output rows inside its box
   // (same arithmetic as mask_upsample_kernel).  Only those are computed and written.
@@ -88,9 +124,9 @@ __global__ __launch_bounds__(256) void mask_gemm_kernel(GemmParams G) {
     if (i < m_b) {
       const float *d = G.det + (size_t)G.slot_map[base + i] * G.det_stride;
       const float bx1 = d[0], by1 = d[1], bx2 = d[2], by2 = d[3];
-      const int ya = max(0, (int)ceilf(by1)), yb = min(G.g.h0, (int)ceilf(by2));
+      const int ya = max(0, (int)ceilf(by1)), yb = min(g.h0, (int)ceilf(by2));
       if (ya < yb && bx1 < bx2) {
-        const float scale_h = (float)wh / (float)G.g.h0;
+        const float scale_h = (float)wh / (float)g.h0;
         int i0, i1; float l0, l1;
         bilinear_src(scale_h, ya, wh, i0, i1, l0, l1);
         lo = i0;
@@ -111,9 +147,9 @@ __global__ __launch_bounds__(256) void mask_gemm_kernel(GemmParams G) {
   __syncthreads();
   const int ulo = runion[0], uhi = runion[1];
   if (ulo > uhi) return;
-  const int npx = wh * G.g.mw;
-  const int plane = G.g.mh * G.g.mw;
-  const float *pb = G.proto + (size_t)b * 32 * plane + (size_t)G.g.top * G.g.mw;
+  const int npx = wh * g.mw;
+  const int plane = g.mh * g.mw;
+  const float *pb = G.proto + (size_t)b * 32 * plane + (size_t)g.top * g.mw;
 
   // A fragments: coef[row0 + (lane&31)][2s + (lane>>5)], s = 0..15
   float a[16];
@@ -136,10 +172,10 @@ __global__ __launch_bounds__(256) void mask_gemm_kernel(GemmParams G) {
   for (int t = 0; t < G.tiles_per_block; ++t) {
     const int p0 = (tile0 + t) * TP;
     if (p0 >= npx) break;
-    if (p0 / G.g.mw > uhi || min(p0 + TP - 1, npx - 1) / G.g.mw < ulo) continue;  // no survivor of this tile reads these rows
+    if (p0 / g.mw > uhi || min(p0 + TP - 1, npx - 1) / g.mw < ulo) continue;  // no survivor of this tile reads these rows
     const int p = p0 + V * (lane & 31);
     const bool pv = p < npx;          // npx % V == 0: a lane's V pixels are valid together and share a row
-    const int prow = p / G.g.mw;
+    const int prow = p / g.mw;
     floatx16 acc[V];
 #pragma unroll
     for (int e = 0; e < V; ++e)
@@ -168,7 +204,7 @@ __global__ __launch_bounds__(256) void mask_gemm_kernel(GemmParams G) {
         const int i = row0 + li;
         const long long slot = (long long)base + i;
         if (i < m_b && slot < G.capacity && prow >= rlo[li] && prow <= rhi[li]) {
-          float *o = G.logits + (size_t)slot * npx + p;
+          float *o = G.logits + (size_t)slot * G.lstride + p;
           if constexpr (V == 4) *reinterpret_cast<float4 *>(o) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
           else *o = acc[0][r];
         }
@@ -196,11 +232,13 @@ __global__ __launch_bounds__(256) void mask_logits_rows_kernel(GemmParams G) {
   const int m_b = G.slot_base[b + 1] - base;
   if (m_b <= 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wh = G.g.bottom - G.g.top, mw = G.g.mw;
+  const MaskGeom g = image_geom(G.M, b);
+  const int wh = g.bottom - g.top, mw = g.mw;
   const int npx = wh * mw;
-  const int plane = G.g.mh * mw;
-  const float *pb = G.proto + (size_t)b * 32 * plane + (size_t)G.g.top * mw;
-  const float scale_h = (float)wh / (float)G.g.h0;
+  const int plane = g.mh * mw;
+  const float *pb = G.proto + (size_t)b * 32 * plane + (size_t)g.top * mw;
+  const float scale_h = (float)wh / (float)g.h0;
+  if (blockIdx.x > 0 && (int)blockIdx.x * 512 >= npx) return;   // ragged batch: the grid spans the largest window
 
   const int p0 = (blockIdx.x * 4 + wave) * 128;
   const int p = p0 + 2 * lane;
@@ -212,7 +250,7 @@ __global__ __launch_bounds__(256) void mask_logits_rows_kernel(GemmParams G) {
   auto row_range = [&](const float *d, int &lo, int &hi) {
     const float bx1 = d[0], by1 = d[1], bx2 = d[2], by2 = d[3];
     lo = 1; hi = 0;
-    const int ya = max(0, (int)ceilf(by1)), yb = min(G.g.h0, (int)ceilf(by2));
+    const int ya = max(0, (int)ceilf(by1)), yb = min(g.h0, (int)ceilf(by2));
     if (ya < yb && bx1 < bx2) {  // same arithmetic as mask_upsample_kernel
       int i0, i1; float l0, l1;
       bilinear_src(scale_h, ya, wh, i0, i1, l0, l1);
@@ -246,7 +284,7 @@ __global__ __launch_bounds__(256) void mask_logits_rows_kernel(GemmParams G) {
       rlo[threadIdx.x] = lo;
       rhi[threadIdx.x] = hi;
       const long long slot = (long long)base + s0 + threadIdx.x;   // the upsample's box pass reads this record
-      if (blockIdx.x == 0 && slot < G.capacity) G.table[slot] = box_ranges(d[0], d[1], d[2], d[3], G.g.h0, G.g.w0);
+      if (blockIdx.x == 0 && slot < G.capacity) G.table[slot] = box_ranges(d[0], d[1], d[2], d[3], g.h0, g.w0);
     }
     __syncthreads();
 
@@ -266,7 +304,7 @@ __global__ __launch_bounds__(256) void mask_logits_rows_kernel(GemmParams G) {
           acc = __builtin_elementwise_fma(cv, bf[4 * k4 + j], acc);
         }
       }
-      if (prow >= lo && prow <= hi) *reinterpret_cast<float2v *>(G.logits + (size_t)slot * npx + p) = acc;
+      if (prow >= lo && prow <= hi) *reinterpret_cast<float2v *>(G.logits + (size_t)slot * G.lstride + p) = acc;
     }
   }
 }
@@ -278,13 +316,18 @@ struct UpParams {
   const float *logits;
   void *out;
   int batch, max_det, det_stride;
-  long long capacity;
-  MaskGeom g;
+  long long capacity;      // slots the output (and the logits workspace) can hold
+  long long out_elems;     // ragged originals: elements the output can hold
+  MaskBatch M;
+  int lstride;             // floats per slot in `logits`
   int rows_per_block;
   int lds_rows;  // logits rows the LDS buffer can hold
   const int4 *table;  // split path: per-slot pixel ranges of the box {xa, xb, ya, yb}
   int *overflow;
 };
+
+// image of a slot: slot_map[slot] = b * max_det + i
+__device__ __forceinline__ int slot_image(const UpParams &U, long long slot) { return U.slot_map[slot] / U.max_det; }
 
 template <typename OutT>
 struct MaskOut;
@@ -335,8 +378,10 @@ struct MaskOut<float> {
 __global__ __launch_bounds__(256) void mask_slot_table_kernel(GemmParams G) {
   const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
   if (s >= min((long long)G.slot_base[G.batch], G.capacity)) return;
-  const float *d = G.det + (size_t)G.slot_map[s] * G.det_stride;
-  G.table[s] = box_ranges(d[0], d[1], d[2], d[3], G.g.h0, G.g.w0);
+  const int e = G.slot_map[s];
+  const float *d = G.det + (size_t)e * G.det_stride;
+  const MaskGeom g = image_geom(G.M, e / G.max_det);
+  G.table[s] = box_ranges(d[0], d[1], d[2], d[3], g.h0, g.w0);
 }
 
 // Zeros for every live slot, written the way that reaches the memset rate on MI355X (profiles/r01/write_ceiling.md):
@@ -346,11 +391,17 @@ __global__ __launch_bounds__(256) void mask_slot_table_kernel(GemmParams G) {
 // of instructions: no box test here -- mask_upsample_kernel (box_only) overwrites the few per cent of chunks that
 // meet a box afterwards.
 __global__ __launch_bounds__(256) void mask_zero_fill_kernel(const int *__restrict__ slot_base, int batch, long long capacity,
-                                                            long long chunks_per_slot, uint4 *__restrict__ out, int *__restrict__ overflow) {
-  const long long total_all = slot_base[batch];
-  if (blockIdx.x == 0 && threadIdx.x == 0 && overflow) *overflow = total_all > capacity ? (int)(total_all - capacity) : 0;
-  const long long total = total_all < capacity ? total_all : capacity;
-  const long long n = total * chunks_per_slot;
+                                                            long long chunks_per_slot, long long ragged_chunks, uint4 *__restrict__ out,
+                                                            int *__restrict__ overflow) {
+  long long n = ragged_chunks;   // ragged originals: the host laid the masks out and knows where they end
+  if (ragged_chunks < 0) {
+    const long long total_all = slot_base[batch];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && overflow) *overflow = total_all > capacity ? (int)(total_all - capacity) : 0;
+    const long long total = total_all < capacity ? total_all : capacity;
+    n = total * chunks_per_slot;
+  } else if (blockIdx.x == 0 && threadIdx.x == 0 && overflow) {
+    *overflow = 0;
+  }
   const long long stride = (long long)gridDim.x * 256;
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
   const u4 zero = {0u, 0u, 0u, 0u};
@@ -373,13 +424,18 @@ __global__ __launch_bounds__(256) void mask_box_kernel(UpParams U) {
 
   const long long slot = blockIdx.y;
   if (slot >= U.slot_base[U.batch]) return;   // beyond the live slots (the grid spans the buffer's capacity)
+  if (slot >= U.capacity) return;
   const int4 t = U.table[slot];               // all zero for a box that holds no pixel
   const int ra = max((int)blockIdx.x * U.rows_per_block, t.z), rb = min(((int)blockIdx.x + 1) * U.rows_per_block, t.w);
   if (ra >= rb) return;           // most workgroups: no row of the box in this strip
-  const int H0 = U.g.h0, W0 = U.g.w0;
-  const int wh = U.g.bottom - U.g.top, ww = U.g.right - U.g.left, mw = U.g.mw;
+  const int b = U.M.images ? slot_image(U, slot) : 0;
+  const MaskGeom g = image_geom(U.M, b);
+  const int H0 = g.h0, W0 = g.w0;
+  const int wh = g.bottom - g.top, ww = g.right - g.left, mw = g.mw;
   const float scale_h = (float)wh / (float)H0, scale_w = (float)ww / (float)W0;
-  OutT *out = reinterpret_cast<OutT *>(U.out) + (size_t)slot * H0 * W0;
+  const long long off = mask_offset(U.M, g, b, slot, U.M.images ? U.slot_base[b] : 0);
+  if (U.M.images && off + (long long)H0 * W0 > U.out_elems) return;
+  OutT *out = reinterpret_cast<OutT *>(U.out) + off;
 
   const int ca = t.x / PX, cb = (t.y + PX - 1) / PX;   // chunk columns that meet the box (rows are whole chunks)
   // Staged: the logits rows this strip's box rows read, and of those only the columns its chunk columns read, plus
@@ -396,7 +452,7 @@ __global__ __launch_bounds__(256) void mask_box_kernel(UpParams U) {
     ly_first = i0;
     bilinear_src(scale_h, rb - 1, wh, j0, j1, l0, l1);
     const int nrows = j1 - ly_first + 1;  // <= U.lds_rows by construction on the host
-    const float *src = U.logits + (size_t)slot * wh * mw + (size_t)ly_first * mw + U.g.left;
+    const float *src = U.logits + (size_t)slot * U.lstride + (size_t)ly_first * mw + g.left;
     for (int idx = threadIdx.x; idx < nrows * ls; idx += 256) {
       const int r = idx / ls, c = idx - r * ls;
       L[idx] = src[(size_t)r * mw + min(c_lo + c, ww - 1)];
@@ -430,8 +486,7 @@ __global__ __launch_bounds__(256) void mask_box_kernel(UpParams U) {
     // registers across the consecutive output rows that share a source row pair (6-7 rows at 1080p from 160x160)
     auto hrow = [&](int iy, int k) -> float {
       const taps a = *reinterpret_cast<const taps *>(reinterpret_cast<const char *>(L + (iy - ly_first) * ls) + oa[k]);
-      const f2 p = f2{a.x, a.y} * wx[k];   // packed fp32 multiply, each half rounded as the scalar form
-      return p.x + p.y;
+      return fmaf(a.x, wx[k].x, a.y * wx[k].y);   // aten: fma(left, w_left, right * w_right)
     };
     f2 tt[PX];   // {upper, lower} source row, interpolated horizontally
     int cur0 = -1, cur1 = -1;
@@ -455,13 +510,10 @@ __global__ __launch_bounds__(256) void mask_box_kernel(UpParams U) {
         }
         cur0 = iy0; cur1 = iy1;
       }
-      const f2 lyv = {ly0, ly1};
       uint32_t bits = 0;
 #pragma unroll
-      for (int k = 0; k < PX; ++k) {
-        const f2 q = tt[k] * lyv;
-        if (q.x + q.y > 0.0f) bits |= 1u << k;
-      }
+      for (int k = 0; k < PX; ++k)
+        if (fmaf(tt[k].x, ly0, tt[k].y * ly1) > 0.0f) bits |= 1u << k;
       OutT *p = out + (size_t)y * W0 + x0;
       MO::store_vec_nt(p, bits & xmask);
     }
@@ -482,14 +534,20 @@ __global__ __launch_bounds__(256) void mask_upsample_kernel(UpParams U) {
     *U.overflow = total > U.capacity ? (int)(total - U.capacity) : 0;  // survivors that did not fit
   if (slot >= total || slot >= U.capacity) return;
   const int e = U.slot_map[slot];
+  const int b = e / U.max_det;
   const float *d = U.det + (size_t)e * U.det_stride;
   const float bx1 = d[0], by1 = d[1], bx2 = d[2], by2 = d[3];
-  const int H0 = U.g.h0, W0 = U.g.w0;
-  const int wh = U.g.bottom - U.g.top, ww = U.g.right - U.g.left, mw = U.g.mw;
+  const MaskGeom g = image_geom(U.M, b);
+  const int H0 = g.h0, W0 = g.w0;
+  const int wh = g.bottom - g.top, ww = g.right - g.left, mw = g.mw;
   const float scale_h = (float)wh / (float)H0, scale_w = (float)ww / (float)W0;
-  OutT *out = reinterpret_cast<OutT *>(U.out) + (size_t)slot * H0 * W0;
+  const long long off = mask_offset(U.M, g, b, slot, U.M.images ? U.slot_base[b] : 0);
+  if (U.M.images && off + (long long)H0 * W0 > U.out_elems) return;
+  OutT *out = reinterpret_cast<OutT *>(U.out) + off;
+  const bool weights4 = H0 + W0 <= 128;   // aten's kernel choice (oracle/geometry.py:aten_linear_variant)
 
   const int y_begin = blockIdx.x * U.rows_per_block;
+  if (y_begin >= H0) return;              // ragged batch: the grid spans the tallest frame
   const int y_end = min(y_begin + U.rows_per_block, H0);
   // rows of this strip that intersect the box: y >= by1 && y < by2
   int ya = max(y_begin, (int)ceilf(by1));
@@ -504,7 +562,7 @@ __global__ __launch_bounds__(256) void mask_upsample_kernel(UpParams U) {
     int j0, j1;
     bilinear_src(scale_h, yb - 1, wh, j0, j1, l0, l1);
     const int nrows = j1 - ly_first + 1;  // <= U.lds_rows by construction on the host
-    const float *src = U.logits + (size_t)slot * wh * mw + (size_t)ly_first * mw + U.g.left;
+    const float *src = U.logits + (size_t)slot * U.lstride + (size_t)ly_first * mw + g.left;
     for (int idx = threadIdx.x; idx < nrows * ww; idx += 256) {
       const int r = idx / ww, c = idx - r * ww;
       L[idx] = src[(size_t)r * mw + c];
@@ -513,7 +571,7 @@ __global__ __launch_bounds__(256) void mask_upsample_kernel(UpParams U) {
   }
 
   const int chunks = (W0 + PX - 1) / PX;
-  const bool vec_ok = (W0 % PX) == 0;
+  const bool vec_ok = (W0 % PX) == 0 && (off % PX) == 0;
   const int nwork = (y_end - y_begin) * chunks;
   for (int wi = threadIdx.x; wi < nwork; wi += 256) {
     const int y = y_begin + wi / chunks;
@@ -534,9 +592,15 @@ __global__ __launch_bounds__(256) void mask_upsample_kernel(UpParams U) {
         if (x < W0 && fx >= bx1 && fx < bx2) {
           int ix0, ix1; float lx0, lx1;
           bilinear_src(scale_w, x, ww, ix0, ix1, lx0, lx1);
-          const float t0 = r0[ix0] * lx0 + r0[ix1] * lx1;
-          const float t1 = r1[ix0] * lx0 + r1[ix1] * lx1;
-          const float v = t0 * ly0 + t1 * ly1;
+          float v;
+          if (weights4) {
+            const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+            v = fmaf(w11, r1[ix1], fmaf(w10, r1[ix0], fmaf(w00, r0[ix0], w01 * r0[ix1])));
+          } else {
+            const float t0 = fmaf(r0[ix0], lx0, r0[ix1] * lx1);
+            const float t1 = fmaf(r1[ix0], lx0, r1[ix1] * lx1);
+            v = fmaf(t0, ly0, t1 * ly1);
+          }
           if (v > 0.0f) bits |= 1u << k;
         }
       }
@@ -549,19 +613,70 @@ __global__ __launch_bounds__(256) void mask_upsample_kernel(UpParams U) {
   }
 }
 
-void crop_window(int mh, int mw, int h0, int w0, MaskGeom &g) {
-  // ultralytics scale_masks: gain = min(mh/h0, mw/w0); pad = (mw - w0*gain)/2, (mh - h0*gain)/2;
-  // top,left = int(pad_y), int(pad_x); bottom,right = int(mh - pad_y), int(mw - pad_x)
-  const double gh = (double)mh / (double)h0, gw = (double)mw / (double)w0;
-  const double gain = gh < gw ? gh : gw;
-  const double pad_x = ((double)mw - (double)w0 * gain) / 2.0;
-  const double pad_y = ((double)mh - (double)h0 * gain) / 2.0;
-  g.mh = mh; g.mw = mw; g.h0 = h0; g.w0 = w0;
-  g.top = (int)pad_y; g.left = (int)pad_x;
-  g.bottom = (int)((double)mh - pad_y); g.right = (int)((double)mw - pad_x);
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// CU count of the current device, asked once per device (the zero fill launches one workgroup per CU)
+int device_cu_count() {
+  static std::mutex mu;
+  static int cache[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  std::lock_guard<std::mutex> lock(mu);
+  if (cache[dev] == 0) {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    cache[dev] = ncu;
+  }
+  return cache[dev];
 }
 
-inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// Validated shape of one call: the batch's geometry for the kernels and its extents for the launch.
+struct MaskCall {
+  MaskBatch M;
+  int max_h0;          // tallest original
+  int max_ww;          // widest crop window
+  int max_wh;          // tallest crop window
+  double max_ratio;    // largest wh / h0: logits rows per output row
+  bool rows_chunked;   // every image: rows and mask starts are whole 16-byte chunks, h0 + w0 > 128
+  long long end_elems; // ragged: one past the last mask element
+};
+
+int mask_check_common(const char *fn, int batch, int nm, int mh, int mw, int h0, int w0, const lmi_mask_image *images_host,
+                      const lmi_mask_image *images_dev, int max_det, int det_stride, int64_t capacity_masks, int px, MaskCall &C) {
+  LMI_REQUIRE(nm == LMI_MAX_MASK_DIM, LMI_ERR_LIMIT, "%s: nm=%d, only %d prototype channels are supported", fn, nm, LMI_MAX_MASK_DIM);
+  LMI_REQUIRE(batch > 0 && batch <= 65535 && mh > 0 && mw > 0 && max_det > 0 && det_stride >= 6 + nm, LMI_ERR_BAD_ARG,
+              "%s: bad shape batch=%d proto=%dx%d max_det=%d det_stride=%d", fn, batch, mh, mw, max_det, det_stride);
+  LMI_REQUIRE(capacity_masks > 0 && capacity_masks <= 65535, LMI_ERR_LIMIT, "%s: capacity_masks %lld not in 1..65535", fn, (long long)capacity_masks);
+  LMI_REQUIRE((images_host == nullptr) == (images_dev == nullptr), LMI_ERR_BAD_ARG, "%s: images_host and images_dev go together", fn);
+  C.M.images = images_dev;
+  C.max_h0 = 0; C.max_ww = 0; C.max_wh = 0; C.max_ratio = 0.0; C.rows_chunked = true; C.end_elems = 0;
+  const int n = images_host ? batch : 1;
+  for (int b = 0; b < n; ++b) {
+    const int ih = images_host ? images_host[b].h0 : h0, iw = images_host ? images_host[b].w0 : w0;
+    LMI_REQUIRE(ih > 0 && iw > 0, LMI_ERR_BAD_ARG, "%s: image %d: bad original size %dx%d", fn, b, ih, iw);
+    MaskGeom g;
+    crop_window(mh, mw, ih, iw, g);
+    const int wh = g.bottom - g.top, ww = g.right - g.left;
+    LMI_REQUIRE(wh > 0 && ww > 0 && g.top >= 0 && g.left >= 0 && g.bottom <= mh && g.right <= mw, LMI_ERR_BAD_ARG, "%s: image %d: empty crop window", fn, b);
+    if (b == 0) C.M.g = g;   // uniform originals: the kernels take it from here
+    if (ih > C.max_h0) C.max_h0 = ih;
+    if (ww > C.max_ww) C.max_ww = ww;
+    if (wh > C.max_wh) C.max_wh = wh;
+    const double ratio = (double)wh / (double)ih;
+    if (ratio > C.max_ratio) C.max_ratio = ratio;
+    bool ok = (iw % px) == 0 && ih + iw > 128;
+    if (images_host) {
+      const lmi_mask_image &im = images_host[b];
+      LMI_REQUIRE(im.n_masks >= 0 && im.out_offset >= 0, LMI_ERR_BAD_ARG, "%s: image %d: negative mask count / offset", fn, b);
+      ok = ok && (im.out_offset % px) == 0;
+      const long long end = (long long)im.out_offset + (long long)im.n_masks * ih * iw;
+      if (im.n_masks > 0 && end > C.end_elems) C.end_elems = end;
+    }
+    C.rows_chunked = C.rows_chunked && ok;
+  }
+  if (images_host) { C.M.g.mh = mh; C.M.g.mw = mw; }
+  return LMI_OK;
+}
 
 }  // namespace
 
@@ -573,161 +688,136 @@ int64_t lmi_mask_workspace_bytes(int64_t capacity_masks, int mh, int mw) {
   return (int64_t)(align_up((size_t)capacity_masks * mh * mw * sizeof(float), 256) + align_up((size_t)capacity_masks * sizeof(int4), 256));
 }
 
-static int mask_check_common(const char *fn, int batch, int nm, int mh, int mw, int h0, int w0, int max_det, int det_stride,
-                             int64_t capacity_masks, MaskGeom &g) {
-  LMI_REQUIRE(nm == LMI_MAX_MASK_DIM, LMI_ERR_LIMIT, "%s: nm=%d, only %d prototype channels are supported", fn, nm, LMI_MAX_MASK_DIM);
-  LMI_REQUIRE(batch > 0 && batch <= 65535 && mh > 0 && mw > 0 && h0 > 0 && w0 > 0 && max_det > 0 && det_stride >= 6 + nm, LMI_ERR_BAD_ARG,
-              "%s: bad shape batch=%d proto=%dx%d orig=%dx%d max_det=%d det_stride=%d", fn, batch, mh, mw, h0, w0, max_det, det_stride);
-  LMI_REQUIRE(capacity_masks > 0 && capacity_masks <= 65535, LMI_ERR_LIMIT, "%s: capacity_masks %lld not in 1..65535", fn, (long long)capacity_masks);
-  crop_window(mh, mw, h0, w0, g);
-  const int wh = g.bottom - g.top, ww = g.right - g.left;
-  LMI_REQUIRE(wh > 0 && ww > 0 && g.top >= 0 && g.left >= 0 && g.bottom <= mh && g.right <= mw, LMI_ERR_BAD_ARG, "%s: empty crop window", fn);
-  return LMI_OK;
-}
-
-int lmi_mask_logits(const float *proto, int batch, int nm, int mh, int mw, const float *det, int max_det, int det_stride,
-                    const int32_t *slot_map, const int32_t *slot_base, int h0, int w0, int64_t capacity_masks,
-                    void *workspace, int64_t workspace_bytes, void *stream) {
+int lmi_mask_logits_ex(const float *proto, int batch, int nm, int mh, int mw, const float *det, int max_det, int det_stride,
+                       const int32_t *slot_map, const int32_t *slot_base, int h0, int w0, const lmi_mask_image *images_host,
+                       const lmi_mask_image *images_dev, int64_t capacity_masks, void *workspace, int64_t workspace_bytes, int flags,
+                       void *stream) {
   LMI_REQUIRE(proto && det && slot_map && slot_base && workspace, LMI_ERR_BAD_ARG, "lmi_mask_logits: NULL pointer");
-  MaskGeom g;
-  int rc = mask_check_common("lmi_mask_logits", batch, nm, mh, mw, h0, w0, max_det, det_stride, capacity_masks, g);
+  MaskCall C;
+  int rc = mask_check_common("lmi_mask_logits", batch, nm, mh, mw, h0, w0, images_host, images_dev, max_det, det_stride, capacity_masks, 1, C);
   if (rc) return rc;
   LMI_REQUIRE(lmi_is_aligned(workspace, 256) && lmi_is_aligned(proto, 4), LMI_ERR_ALIGNMENT, "lmi_mask_logits: workspace must be 256-byte aligned");
   LMI_REQUIRE(workspace_bytes >= lmi_mask_workspace_bytes(capacity_masks, mh, mw), LMI_ERR_WORKSPACE, "lmi_mask_logits: workspace %lld < %lld bytes",
               (long long)workspace_bytes, (long long)lmi_mask_workspace_bytes(capacity_masks, mh, mw));
   GemmParams G;
   G.proto = proto; G.det = det; G.slot_map = slot_map; G.slot_base = slot_base; G.logits = reinterpret_cast<float *>(workspace);
-  G.batch = batch; G.max_det = max_det; G.det_stride = det_stride; G.capacity = capacity_masks; G.g = g;
+  G.batch = batch; G.max_det = max_det; G.det_stride = det_stride; G.capacity = capacity_masks; G.M = C.M; G.lstride = mh * mw;
   G.table = reinterpret_cast<int4 *>(reinterpret_cast<char *>(workspace) + align_up((size_t)capacity_masks * mh * mw * sizeof(float), 256));
-  const int npx = (g.bottom - g.top) * mw;
-  // LMI_MASK_LOGITS=mfma selects the dense MFMA tiles for every shape (a measurement knob: bench.py --mask-logits mfma)
-  const char *mode = getenv("LMI_MASK_LOGITS");
-  const bool force_mfma = mode && strcmp(mode, "mfma") == 0;
-  if (!force_mfma && (mw % 2) == 0 && lmi_is_aligned(proto, 8)) {
+  const int npx = C.max_wh * mw;   // the largest window of the batch; tiles beyond an image's own window leave at once
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (!(flags & LMI_MASK_LOGITS_MFMA) && (mw % 2) == 0 && lmi_is_aligned(proto, 8)) {
     const int tiles = (npx + 127) / 128;
-    hipLaunchKernelGGL(mask_logits_rows_kernel, dim3((tiles + 3) / 4, batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
+    hipLaunchKernelGGL(mask_logits_rows_kernel, dim3((tiles + 3) / 4, batch), dim3(256), 0, s, G);
     return lmi_check_launch("mask_logits_rows_kernel");
   }
-  hipLaunchKernelGGL(mask_slot_table_kernel, dim3((unsigned)((capacity_masks + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
+  hipLaunchKernelGGL(mask_slot_table_kernel, dim3((unsigned)((capacity_masks + 255) / 256)), dim3(256), 0, s, G);
   // dense MFMA tiles: 4 adjacent pixels per lane when rows are whole 16-byte vectors, else one pixel per lane
   const bool vec4 = (mw % 4) == 0 && lmi_is_aligned(proto, 16);
   const int ntiles = (npx + (vec4 ? 127 : 31)) / (vec4 ? 128 : 32);
   G.tiles_per_block = vec4 ? 1 : 4;
   const int gx = (ntiles + 4 * G.tiles_per_block - 1) / (4 * G.tiles_per_block);
   dim3 ggrid(gx, (max_det + 31) / 32, batch);
-  if (vec4) hipLaunchKernelGGL(mask_gemm_kernel<4>, ggrid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
-  else hipLaunchKernelGGL(mask_gemm_kernel<1>, ggrid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
+  if (vec4) hipLaunchKernelGGL(mask_gemm_kernel<4>, ggrid, dim3(256), 0, s, G);
+  else hipLaunchKernelGGL(mask_gemm_kernel<1>, ggrid, dim3(256), 0, s, G);
   return lmi_check_launch("mask_gemm_kernel");
 }
 
-namespace {
-
-struct UpCall {
-  UpParams U;
-  MaskGeom g;
-  hipStream_t s;
-  int px;       // pixels per 16-byte chunk
-  bool split;   // rows are whole chunks: zero fill + box pass
-};
-
-int up_setup(const char *fn, void *workspace, int batch, int nm, int mh, int mw, const float *det, int max_det, int det_stride,
-             const int32_t *slot_map, const int32_t *slot_base, int h0, int w0, void *out_masks, int out_dtype,
-             int64_t capacity_masks, int32_t *overflow, void *stream, UpCall &C) {
-  LMI_REQUIRE(workspace && det && slot_map && slot_base && out_masks, LMI_ERR_BAD_ARG, "%s: NULL pointer", fn);
-  int rc = mask_check_common(fn, batch, nm, mh, mw, h0, w0, max_det, det_stride, capacity_masks, C.g);
-  if (rc) return rc;
-  LMI_REQUIRE(out_dtype == LMI_U8 || out_dtype == LMI_F32, LMI_ERR_BAD_ARG, "%s: out_dtype must be LMI_U8 or LMI_F32", fn);
-  LMI_REQUIRE(lmi_is_aligned(out_masks, 16) && lmi_is_aligned(workspace, 256), LMI_ERR_ALIGNMENT,
-              "%s: out_masks must be 16-byte and workspace 256-byte aligned", fn);
-  UpParams &U = C.U;
-  U.det = det; U.slot_map = slot_map; U.slot_base = slot_base; U.logits = reinterpret_cast<const float *>(workspace); U.out = out_masks;
-  U.batch = batch; U.max_det = max_det; U.det_stride = det_stride; U.capacity = capacity_masks; U.g = C.g; U.overflow = overflow;
-  U.table = reinterpret_cast<int4 *>(reinterpret_cast<char *>(workspace) + align_up((size_t)capacity_masks * mh * mw * sizeof(float), 256));
-  U.rows_per_block = 0; U.lds_rows = 0;
-  C.s = reinterpret_cast<hipStream_t>(stream);
-  C.px = out_dtype == LMI_U8 ? 16 : 4;
-  C.split = (w0 % C.px) == 0;
-  return LMI_OK;
-}
-
 // rows per strip: the largest power of two <= start whose staged logits rows fit 48 KiB of LDS
-int up_strip(UpCall &C, int start, int extra_cols) {
-  const int wh = C.g.bottom - C.g.top, ww = C.g.right - C.g.left;
+static int up_strip(const MaskCall &C, UpParams &U, int start, int extra_cols) {
   int rpb = start, lds_rows = 0;
   for (;; rpb >>= 1) {
-    lds_rows = (int)((double)rpb * (double)wh / (double)C.g.h0) + 3;
-    if (lds_rows > wh) lds_rows = wh;
-    if ((size_t)lds_rows * (ww + extra_cols) * sizeof(float) <= 48 * 1024 || rpb == 1) break;
+    lds_rows = (int)((double)rpb * C.max_ratio) + 3;
+    if (lds_rows > C.M.g.mh) lds_rows = C.M.g.mh;
+    if ((size_t)lds_rows * (C.max_ww + extra_cols) * sizeof(float) <= 48 * 1024 || rpb == 1) break;
   }
-  if ((size_t)lds_rows * (ww + extra_cols) * sizeof(float) > 64 * 1024) {
-    lmi_set_error("lmi_mask_upsample: prototype rows too wide for LDS (%d)", ww);
+  if ((size_t)lds_rows * (C.max_ww + extra_cols) * sizeof(float) > 64 * 1024) {
+    lmi_set_error("lmi_mask_upsample: prototype rows too wide for LDS (%d)", C.max_ww);
     return LMI_ERR_LIMIT;
   }
-  C.U.rows_per_block = rpb; C.U.lds_rows = lds_rows;
+  U.rows_per_block = rpb; U.lds_rows = lds_rows;
   return LMI_OK;
 }
 
-// zeros for every live slot at the memset rate: one workgroup per CU, the compact write window (see the kernel)
-int up_fill(const int32_t *slot_base, int batch, int h0, int w0, int px, void *out_masks, int64_t capacity_masks, int32_t *overflow,
-            hipStream_t s) {
-  int ncu = 256, dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
-    ncu = 256;
-  hipLaunchKernelGGL(mask_zero_fill_kernel, dim3(ncu), dim3(256), 0, s, slot_base, batch, (long long)capacity_masks,
-                     (long long)h0 * (w0 / px), reinterpret_cast<uint4 *>(out_masks), overflow);
-  return lmi_check_launch("mask_zero_fill_kernel");
-}
-
-// the chunks that meet a box; ALU-bound, not store-bound: tall strips, so that a lane's horizontal taps serve many rows
-int up_boxes(UpCall &C, int out_dtype) {
-  int rc = up_strip(C, 256, 1);
+int lmi_mask_upsample_ex(void *workspace, int batch, int nm, int mh, int mw, const float *det, int max_det, int det_stride,
+                         const int32_t *slot_map, const int32_t *slot_base, int h0, int w0, const lmi_mask_image *images_host,
+                         const lmi_mask_image *images_dev, void *out_masks, int out_dtype, int64_t capacity_masks, int64_t out_elems,
+                         int32_t *overflow, int flags, void *stream) {
+  const char *fn = "lmi_mask_upsample";
+  LMI_REQUIRE(workspace && det && slot_map && slot_base && out_masks, LMI_ERR_BAD_ARG, "%s: NULL pointer", fn);
+  LMI_REQUIRE(out_dtype == LMI_U8 || out_dtype == LMI_F32, LMI_ERR_BAD_ARG, "%s: out_dtype must be LMI_U8 or LMI_F32", fn);
+  const int px = out_dtype == LMI_U8 ? 16 : 4;   // pixels per 16-byte chunk
+  MaskCall C;
+  int rc = mask_check_common(fn, batch, nm, mh, mw, h0, w0, images_host, images_dev, max_det, det_stride, capacity_masks, px, C);
   if (rc) return rc;
-  const size_t lds = (size_t)C.U.lds_rows * (C.g.right - C.g.left + 1) * sizeof(float);
-  dim3 grid((C.g.h0 + C.U.rows_per_block - 1) / C.U.rows_per_block, (unsigned)C.U.capacity);
-  if (out_dtype == LMI_U8)
-    hipLaunchKernelGGL(mask_box_kernel<uint8_t>, grid, dim3(256), lds, C.s, C.U);
-  else
-    hipLaunchKernelGGL(mask_box_kernel<float>, grid, dim3(256), lds, C.s, C.U);
-  return lmi_check_launch("mask_box_kernel");
+  LMI_REQUIRE(lmi_is_aligned(out_masks, 16) && lmi_is_aligned(workspace, 256), LMI_ERR_ALIGNMENT,
+              "%s: out_masks must be 16-byte and workspace 256-byte aligned", fn);
+  LMI_REQUIRE(images_host == nullptr || C.end_elems <= out_elems, LMI_ERR_WORKSPACE, "%s: the masks end at element %lld, out_masks holds %lld",
+              fn, (long long)C.end_elems, (long long)out_elems);
+  UpParams U;
+  U.det = det; U.slot_map = slot_map; U.slot_base = slot_base; U.logits = reinterpret_cast<const float *>(workspace); U.out = out_masks;
+  U.batch = batch; U.max_det = max_det; U.det_stride = det_stride; U.capacity = capacity_masks; U.out_elems = out_elems; U.M = C.M;
+  U.lstride = mh * mw; U.overflow = overflow;
+  U.table = reinterpret_cast<int4 *>(reinterpret_cast<char *>(workspace) + align_up((size_t)capacity_masks * mh * mw * sizeof(float), 256));
+  U.rows_per_block = 0; U.lds_rows = 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+
+  // Split path (rows are whole 16-byte chunks): zeros for every live slot at the memset rate -- one workgroup per
+  // CU, the compact write window -- then mask_box_kernel overwrites only the chunks that meet a box (ALU-bound, not
+  // store-bound: tall strips, so that a lane's horizontal taps serve many rows).
+  if (C.rows_chunked && !(flags & LMI_MASK_UPSAMPLE_SINGLE)) {
+    const long long ragged_chunks = images_host ? (C.end_elems + px - 1) / px : -1;
+    hipLaunchKernelGGL(mask_zero_fill_kernel, dim3(device_cu_count()), dim3(256), 0, s, slot_base, batch, (long long)capacity_masks,
+                       (long long)C.M.g.h0 * (C.M.g.w0 / px), ragged_chunks, reinterpret_cast<uint4 *>(out_masks), overflow);
+    rc = lmi_check_launch("mask_zero_fill_kernel");
+    if (rc) return rc;
+    rc = up_strip(C, U, 256, 1);
+    if (rc) return rc;
+    const size_t lds = (size_t)U.lds_rows * (C.max_ww + 1) * sizeof(float);
+    dim3 grid((C.max_h0 + U.rows_per_block - 1) / U.rows_per_block, (unsigned)capacity_masks);
+    if (out_dtype == LMI_U8) hipLaunchKernelGGL(mask_box_kernel<uint8_t>, grid, dim3(256), lds, s, U);
+    else hipLaunchKernelGGL(mask_box_kernel<float>, grid, dim3(256), lds, s, U);
+    return lmi_check_launch("mask_box_kernel");
+  }
+  rc = up_strip(C, U, 16, 0);
+  if (rc) return rc;
+  const size_t lds = (size_t)U.lds_rows * C.max_ww * sizeof(float);
+  dim3 ugrid((C.max_h0 + U.rows_per_block - 1) / U.rows_per_block, (unsigned)capacity_masks);
+  if (out_dtype == LMI_U8) hipLaunchKernelGGL(mask_upsample_kernel<uint8_t>, ugrid, dim3(256), lds, s, U);
+  else hipLaunchKernelGGL(mask_upsample_kernel<float>, ugrid, dim3(256), lds, s, U);
+  return lmi_check_launch("mask_upsample_kernel");
 }
 
-}  // namespace
+int lmi_process_mask_ex(const float *proto, int batch, int nm, int mh, int mw, const float *det, int max_det, int det_stride,
+                        const int32_t *slot_map, const int32_t *slot_base, int h0, int w0, const lmi_mask_image *images_host,
+                        const lmi_mask_image *images_dev, void *out_masks, int out_dtype, int64_t capacity_masks, int64_t out_elems,
+                        int32_t *overflow, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
+  int rc = lmi_mask_logits_ex(proto, batch, nm, mh, mw, det, max_det, det_stride, slot_map, slot_base, h0, w0, images_host, images_dev,
+                              capacity_masks, workspace, workspace_bytes, flags, stream);
+  if (rc) return rc;
+  return lmi_mask_upsample_ex(workspace, batch, nm, mh, mw, det, max_det, det_stride, slot_map, slot_base, h0, w0, images_host, images_dev,
+                              out_masks, out_dtype, capacity_masks, out_elems, overflow, flags, stream);
+}
+
+int lmi_mask_logits(const float *proto, int batch, int nm, int mh, int mw, const float *det, int max_det, int det_stride,
+                    const int32_t *slot_map, const int32_t *slot_base, int h0, int w0, int64_t capacity_masks,
+                    void *workspace, int64_t workspace_bytes, void *stream) {
+  return lmi_mask_logits_ex(proto, batch, nm, mh, mw, det, max_det, det_stride, slot_map, slot_base, h0, w0, nullptr, nullptr,
+                            capacity_masks, workspace, workspace_bytes, 0, stream);
+}
 
 int lmi_mask_upsample(void *workspace, int batch, int nm, int mh, int mw, const float *det, int max_det, int det_stride,
                       const int32_t *slot_map, const int32_t *slot_base, int h0, int w0, void *out_masks, int out_dtype,
                       int64_t capacity_masks, int32_t *overflow, void *stream) {
-  UpCall C;
-  int rc = up_setup("lmi_mask_upsample", workspace, batch, nm, mh, mw, det, max_det, det_stride, slot_map, slot_base, h0, w0, out_masks,
-                    out_dtype, capacity_masks, overflow, stream, C);
-  if (rc) return rc;
-  // Split path (rows are whole 16-byte chunks): zeros for every live slot at the memset rate, then mask_box_kernel
-  // overwrites only the chunks that meet a box.  LMI_MASK_UPSAMPLE=single keeps the one-kernel path (measurement).
-  const char *single = getenv("LMI_MASK_UPSAMPLE");
-  if (C.split && !(single && strcmp(single, "single") == 0)) {
-    rc = up_fill(slot_base, batch, h0, w0, C.px, out_masks, capacity_masks, overflow, C.s);
-    if (rc) return rc;
-    return up_boxes(C, out_dtype);
-  }
-  rc = up_strip(C, 16, 0);
-  if (rc) return rc;
-  const size_t lds = (size_t)C.U.lds_rows * (C.g.right - C.g.left) * sizeof(float);
-  dim3 ugrid((h0 + C.U.rows_per_block - 1) / C.U.rows_per_block, (unsigned)capacity_masks);
-  if (out_dtype == LMI_U8)
-    hipLaunchKernelGGL(mask_upsample_kernel<uint8_t>, ugrid, dim3(256), lds, C.s, C.U);
-  else
-    hipLaunchKernelGGL(mask_upsample_kernel<float>, ugrid, dim3(256), lds, C.s, C.U);
-  return lmi_check_launch("mask_upsample_kernel");
+  return lmi_mask_upsample_ex(workspace, batch, nm, mh, mw, det, max_det, det_stride, slot_map, slot_base, h0, w0, nullptr, nullptr,
+                              out_masks, out_dtype, capacity_masks, 0, overflow, 0, stream);
 }
 
 int lmi_process_mask(const float *proto, int batch, int nm, int mh, int mw, const float *det, int max_det,
                      int det_stride, const int32_t *slot_map, const int32_t *slot_base, int h0, int w0,
                      void *out_masks, int out_dtype, int64_t capacity_masks, int32_t *overflow, void *workspace,
                      int64_t workspace_bytes, void *stream) {
-  int rc = lmi_mask_logits(proto, batch, nm, mh, mw, det, max_det, det_stride, slot_map, slot_base, h0, w0, capacity_masks,
-                           workspace, workspace_bytes, stream);
-  if (rc) return rc;
-  return lmi_mask_upsample(workspace, batch, nm, mh, mw, det, max_det, det_stride, slot_map, slot_base, h0, w0, out_masks,
-                           out_dtype, capacity_masks, overflow, stream);
+  return lmi_process_mask_ex(proto, batch, nm, mh, mw, det, max_det, det_stride, slot_map, slot_base, h0, w0, nullptr, nullptr,
+                             out_masks, out_dtype, capacity_masks, 0, overflow, workspace, workspace_bytes, 0, stream);
 }
 
 }  // extern "C"

@@ -346,55 +346,119 @@ def scale_coords(det: torch.Tensor, count: torch.Tensor, nkpt: int, ndim: int, m
     return det
 
 
-def process_mask(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.Tensor, slot_base: torch.Tensor,
-                 orig_hw: Tuple[int, int], capacity: int, out_dtype: torch.dtype = torch.uint8,
-                 out: Optional[torch.Tensor] = None, split_events=None, before_upsample=None):
-    """`process_mask_native` + `masks[M]` for the whole batch (uniform original size).
+def _mask_flags(logits: str, upsample: str) -> int:
+    if logits not in ("rows", "mfma") or upsample not in ("split", "single"):
+        raise ValueError("process_mask: logits must be 'rows' | 'mfma', upsample 'split' | 'single'")
+    return (_lib.LMI_MASK_LOGITS_MFMA if logits == "mfma" else 0) | (_lib.LMI_MASK_UPSAMPLE_SINGLE if upsample == "single" else 0)
 
-    Returns (masks (capacity,H0,W0) of uint8|float32 in slot order, overflow (1,) int32).
-    split_events: optional (start, end) torch.cuda.Event pair recorded around the upsample stage
-    alone (the two halves are then enqueued through lmi_mask_logits / lmi_mask_upsample).
-    before_upsample: optional callable run between the two halves (e.g. joining another stream: nothing should run
-    beside the upsample's zero fill, see profiles/r01/write_ceiling.md)."""
-    _need_cuda(proto, "proto")
-    if proto.dtype != torch.float32:
-        proto = proto.float()
-    if not proto.is_contiguous():
-        proto = proto.contiguous()
-    b, nm, mh, mw = proto.shape
-    _, max_det, stride = det.shape
-    h0, w0 = int(orig_hw[0]), int(orig_hw[1])
-    # ultralytics' scale_masks crops the letterbox pad off the prototype window before interpolating; for an extremely
-    # thin frame that window is empty and F.interpolate raises -- same exception type and wording here
+
+def _check_window(mh: int, mw: int, h0: int, w0: int) -> None:
+    """ultralytics' scale_masks crops the letterbox pad off the prototype window before interpolating; for an extremely
+    thin frame that window is empty and F.interpolate raises -- same exception type and wording here."""
     gain = min(mh / h0, mw / w0)
     pad_x, pad_y = (mw - w0 * gain) / 2, (mh - h0 * gain) / 2
     wh_, ww_ = int(mh - pad_y) - int(pad_y), int(mw - pad_x) - int(pad_x)
     if wh_ <= 0 or ww_ <= 0:
         raise RuntimeError(f"Input and output sizes should be greater than 0, but got input (H: {max(wh_, 0)}, W: {max(ww_, 0)}) "
                            f"output (H: {h0}, W: {w0})")
+
+
+def _mask_inputs(proto, det, slot_map, slot_base):
+    _need_cuda(proto, "proto")
+    if proto.dtype != torch.float32:
+        proto = proto.float()
+    if not proto.is_contiguous():
+        proto = proto.contiguous()
+    for t, name, dt in ((det, "det", torch.float32), (slot_map, "slot_map", torch.int32), (slot_base, "slot_base", torch.int32)):
+        _need_cuda(t, name)
+        if t.dtype != dt or not t.is_contiguous() or t.device != proto.device:
+            raise ValueError(f"process_mask: {name} must be a contiguous {dt} tensor on the prototypes' device")
+    if det.ndim != 3 or det.shape[0] != proto.shape[0] or slot_base.numel() != proto.shape[0] + 1:
+        raise ValueError("process_mask: det must be (B,max_det,6+nm) and slot_base (B+1,)")
+    return proto
+
+
+def process_mask(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.Tensor, slot_base: torch.Tensor,
+                 orig_hw: Tuple[int, int], capacity: int, out_dtype: torch.dtype = torch.uint8,
+                 out: Optional[torch.Tensor] = None, split_events=None, before_upsample=None, logits: str = "rows",
+                 upsample: str = "split"):
+    """`process_mask_native` + `masks[M]` for the whole batch (uniform original size).
+
+    Returns (masks (capacity,H0,W0) of uint8|float32 in slot order, overflow (1,) int32).
+    split_events: optional (start, end) torch.cuda.Event pair recorded around the upsample stage
+    alone (the two halves are then enqueued through lmi_mask_logits / lmi_mask_upsample).
+    before_upsample: optional callable run between the two halves (e.g. joining another stream: nothing should run
+    beside the upsample's zero fill, see profiles/r01/write_ceiling.md).
+    logits='mfma' / upsample='single' select the dense MFMA product / the one-pass upsample kernel (measurement)."""
+    proto = _mask_inputs(proto, det, slot_map, slot_base)
+    b, nm, mh, mw = proto.shape
+    _, max_det, stride = det.shape
+    h0, w0 = int(orig_hw[0]), int(orig_hw[1])
+    _check_window(mh, mw, h0, w0)
     ldt = {torch.uint8: LMI_U8, torch.float32: LMI_F32}[out_dtype]
     capacity = max(int(capacity), 1)
     if out is None:
         out = torch.empty((capacity, h0, w0), dtype=out_dtype, device=proto.device)
+    elif tuple(out.shape) != (capacity, h0, w0) or out.dtype != out_dtype or not out.is_contiguous() or out.device != proto.device:
+        raise ValueError(f"process_mask: `out` must be a contiguous {out_dtype} tensor of shape {(capacity, h0, w0)} on the prototypes' device")
     overflow = torch.empty((1,), dtype=torch.int32, device=proto.device)
     nbytes = int(_L.lmi_mask_workspace_bytes(capacity, mh, mw))
     ws = _ws.get(proto.device, "mask", nbytes)
+    flags, st = _mask_flags(logits, upsample), _stream(proto.device)
     if split_events is None and before_upsample is None:
-        check(_L.lmi_process_mask(proto.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
-                                  slot_base.data_ptr(), h0, w0, out.data_ptr(), ldt, capacity, overflow.data_ptr(),
-                                  ws.data_ptr(), ws.numel(), _stream(proto.device)))
+        check(_L.lmi_process_mask_ex(proto.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
+                                     slot_base.data_ptr(), h0, w0, None, None, out.data_ptr(), ldt, capacity, 0, overflow.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), flags, st))
     else:
-        check(_L.lmi_mask_logits(proto.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
-                                 slot_base.data_ptr(), h0, w0, capacity, ws.data_ptr(), ws.numel(), _stream(proto.device)))
+        check(_L.lmi_mask_logits_ex(proto.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
+                                    slot_base.data_ptr(), h0, w0, None, None, capacity, ws.data_ptr(), ws.numel(), flags, st))
         if before_upsample is not None:
             before_upsample()
         if split_events is not None:
             split_events[0].record()
-        check(_L.lmi_mask_upsample(ws.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
-                                   slot_base.data_ptr(), h0, w0, out.data_ptr(), ldt, capacity, overflow.data_ptr(), _stream(proto.device)))
+        check(_L.lmi_mask_upsample_ex(ws.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
+                                      slot_base.data_ptr(), h0, w0, None, None, out.data_ptr(), ldt, capacity, 0, overflow.data_ptr(),
+                                      flags, _stream(proto.device)))
         if split_events is not None:
             split_events[1].record()
     return out, overflow
+
+
+def process_mask_ragged(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.Tensor, slot_base: torch.Tensor,
+                        sizes: Sequence[Tuple[int, int]], counts: Sequence[int], out_dtype: torch.dtype = torch.uint8,
+                        logits: str = "rows", upsample: str = "split") -> List[torch.Tensor]:
+    """`process_mask_native` + `masks[M]` for a batch of DIFFERENTLY sized originals in one launch (the reference loops
+    over the images, object_detectors/yolov8_lmi/model.py:215-236).  sizes[b] = (H0, W0); counts[b] = survivors of
+    image b as read from slot_base (the caller synchronised to size its outputs anyway).  The masks are packed into
+    one flat buffer, every image's block starting on a 16-element boundary; returns the per-image views
+    [(counts[b], H0_b, W0_b)], empty images included."""
+    proto = _mask_inputs(proto, det, slot_map, slot_base)
+    b, nm, mh, mw = proto.shape
+    _, max_det, stride = det.shape
+    if len(sizes) != b or len(counts) != b:
+        raise ValueError("process_mask_ragged: one size and one count per image")
+    ldt = {torch.uint8: LMI_U8, torch.float32: LMI_F32}[out_dtype]
+    desc = (_lib.lmi_mask_image * b)()
+    off = 0
+    for i, ((h0, w0), n) in enumerate(zip(sizes, counts)):
+        h0, w0, n = int(h0), int(w0), int(n)
+        _check_window(mh, mw, h0, w0)
+        desc[i] = _lib.lmi_mask_image(h0, w0, n, 0, off)
+        off = (off + n * h0 * w0 + 15) & ~15
+    total = int(sum(int(c) for c in counts))
+    dev = proto.device
+    flat = torch.empty((max(off, 16),), dtype=out_dtype, device=dev)
+    views = [flat[d.out_offset:d.out_offset + d.n_masks * d.h0 * d.w0].view(d.n_masks, d.h0, d.w0) for d in desc]
+    if total == 0:
+        return views
+    ddev = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).to(dev)
+    ws = _ws.get(dev, "mask", int(_L.lmi_mask_workspace_bytes(total, mh, mw)))
+    st = _stream(dev)
+    check(_L.lmi_process_mask_ex(proto.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
+                                 slot_base.data_ptr(), 0, 0, C.addressof(desc), ddev.data_ptr(), flat.data_ptr(), ldt, total, flat.numel(),
+                                 None, ws.data_ptr(), ws.numel(), _mask_flags(logits, upsample), st))
+    ddev.record_stream(torch.cuda.current_stream(dev))
+    return views
 
 
 def point_ops(operations: Sequence[dict]):

@@ -238,7 +238,7 @@ def test_nms_halves_equal_the_one_call_form(ops, rotated):
 
 def test_mask_upsample_two_pass_form_equals_single_pass_and_oracle(ops):
     """Rows of whole 16-byte chunks take the zero-fill + box-pass form of lmi_mask_upsample: against the one-kernel
-    form (LMI_MASK_UPSAMPLE=single, read per call) bit for bit and against the oracle, on the layouts that stress
+    form (flag LMI_MASK_UPSAMPLE_SINGLE) bit for bit and against the oracle, on the layouts that stress
     it: full-frame and out-of-frame boxes, empty boxes, > 256 chunk columns (fp32, 4K-wide rows), frames smaller
     than the prototype window, and a buffer with more capacity than survivors (dead slots stay untouched)."""
     import os
@@ -271,11 +271,7 @@ def test_mask_upsample_two_pass_form_equals_single_pass_and_oracle(ops):
         two = torch.full((capacity, h0, w0), fill, dtype=dtype, device="cuda")
         one = torch.full((capacity, h0, w0), fill, dtype=dtype, device="cuda")
         ops.process_mask(*args, out=two)
-        os.environ["LMI_MASK_UPSAMPLE"] = "single"
-        try:
-            ops.process_mask(*args, out=one)
-        finally:
-            del os.environ["LMI_MASK_UPSAMPLE"]
+        ops.process_mask(*args, out=one, upsample="single")
         torch.cuda.synchronize()
         assert torch.equal(two, one), f"case {ci}"
         assert bool((two[total:] == fill).all()), f"case {ci}: dead slots were written"

@@ -1,0 +1,107 @@
+"""Masks for a batch of DIFFERENTLY sized originals in one launch (lmi_process_mask_ex with a table of images;
+object_detectors/yolov8_lmi/model.py:215-236 loops over such a list), and the interpolation arithmetic itself
+bit for bit against torch-CPU's F.interpolate."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from object_detectors_amd import synth
+from oracle import masks as OM
+
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    from object_detectors_amd import hip_ops
+    return hip_ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def scene(rng, sizes, counts, max_det, nm=32):
+    B = len(sizes)
+    det = np.zeros((B, max_det, 6 + nm), F32)
+    for b, ((h0, w0), n) in enumerate(zip(sizes, counts)):
+        x1 = rng.random(n) * w0 * 0.6 - 2
+        y1 = rng.random(n) * h0 * 0.6 - 2
+        det[b, :n, 0], det[b, :n, 1] = x1, y1
+        det[b, :n, 2] = np.minimum(x1 + rng.uniform(0.05, 0.5, n) * w0, w0)
+        det[b, :n, 3] = np.minimum(y1 + rng.uniform(0.05, 0.5, n) * h0, h0)
+        det[b, :n, 4] = 0.9
+        det[b, :n, 6:] = rng.normal(0, 0.5, (n, nm))
+    sm = np.full(B * max_det, -1, np.int32)
+    sb = [0]
+    for b, n in enumerate(counts):
+        sm[sb[-1]:sb[-1] + n] = b * max_det + np.arange(n)
+        sb.append(sb[-1] + n)
+    return det, sm, np.array(sb, np.int32)
+
+
+@pytest.mark.parametrize("out_dtype", [torch.uint8, torch.float32])
+def test_ragged_batch_equals_per_image_calls_and_oracle(ops, out_dtype):
+    rng = np.random.default_rng(61)
+    # eight sizes: landscape, portrait, 4K, tiny, a width that is not a whole 16-byte chunk is in the second test
+    sizes = [(1080, 1920), (480, 640), (640, 480), (2160, 3840), (720, 1280), (368, 496), (1200, 1600), (144, 256)]
+    counts = [7, 3, 0, 2, 9, 4, 1, 5]
+    B, mh, mw, max_det = len(sizes), 160, 160, 16
+    proto = synth.proto(rng, B, 32, mh, mw)
+    det, sm, sb = scene(rng, sizes, counts, max_det)
+    views = ops.process_mask_ragged(dev(proto), dev(det), dev(sm), dev(sb), sizes, counts, out_dtype)
+    assert [tuple(v.shape) for v in views] == [(n, h, w) for (h, w), n in zip(sizes, counts)]
+    for b, ((h0, w0), n) in enumerate(zip(sizes, counts)):
+        if n == 0:
+            continue
+        # the same image alone through the uniform entry: bit for bit
+        sm1 = np.full(max_det, -1, np.int32)
+        sm1[:n] = np.arange(n)
+        one, _ = ops.process_mask(dev(proto[b:b + 1]), dev(det[b:b + 1]), dev(sm1), dev(np.array([0, n], np.int32)), (h0, w0), n, out_dtype)
+        assert torch.equal(views[b], one), b
+        ref = OM.process_mask_native(proto[b], det[b, :n, 6:], det[b, :n, :4], (h0, w0))
+        assert ref.sum() > 0 and OM.mask_iou(views[b].cpu().numpy(), ref) >= 0.999, b
+
+
+def test_ragged_batch_with_unaligned_widths_takes_the_one_pass_kernel(ops):
+    rng = np.random.default_rng(62)
+    sizes = [(375, 500), (101, 67), (480, 640), (60, 60)]     # 500 and 67 are not whole chunks; 60 + 60 <= 128: aten's 4-weight kernel
+    counts = [4, 3, 2, 3]
+    B, mh, mw, max_det = len(sizes), 40, 40, 8
+    proto = synth.proto(rng, B, 32, mh, mw)
+    det, sm, sb = scene(rng, sizes, counts, max_det)
+    for upsample in ("split", "single"):
+        views = ops.process_mask_ragged(dev(proto), dev(det), dev(sm), dev(sb), sizes, counts, torch.uint8, upsample=upsample)
+        for b, ((h0, w0), n) in enumerate(zip(sizes, counts)):
+            ref = OM.process_mask_native(proto[b], det[b, :n, 6:], det[b, :n, :4], (h0, w0))
+            assert OM.mask_iou(views[b].cpu().numpy(), ref) >= 0.999, b
+    with pytest.raises(ValueError):
+        ops.process_mask_ragged(dev(proto), dev(det), dev(sm), dev(sb), sizes[:2], counts[:2])
+    none = ops.process_mask_ragged(dev(proto), dev(det), dev(sm), dev(np.zeros(B + 1, np.int32)), sizes, [0] * B)
+    assert [tuple(v.shape) for v in none] == [(0, h, w) for h, w in sizes]
+
+
+@pytest.mark.parametrize("h0,w0,mh,mw", [(1080, 1920, 160, 160), (375, 500, 160, 160), (270, 480, 40, 40), (60, 60, 40, 40),
+                                         (2160, 3840, 160, 160), (640, 640, 160, 160), (97, 131, 52, 40)])
+def test_interpolation_is_bit_exact_against_torch_cpu(ops, h0, w0, mh, mw):
+    """With one-hot coefficients the logits ARE prototype planes (1*p + 0*... is exact), so every difference left
+    would come from the crop window, the bilinear arithmetic, the box crop or the threshold: none is allowed."""
+    rng = np.random.default_rng(h0 + w0)
+    n = 6
+    proto = synth.proto(rng, 1, 32, mh, mw)
+    det = np.zeros((1, n, 38), F32)
+    det[0, :, 0] = rng.uniform(-3, w0 * 0.3, n)
+    det[0, :, 1] = rng.uniform(-3, h0 * 0.3, n)
+    det[0, :, 2] = w0 - rng.uniform(-3, w0 * 0.3, n)
+    det[0, :, 3] = h0 - rng.uniform(-3, h0 * 0.3, n)
+    det[0, np.arange(n), 6 + rng.integers(0, 32, n)] = 1.0
+    sm, sb = np.arange(n, dtype=np.int32), np.array([0, n], np.int32)
+    ref = OM.process_mask_native(proto[0], det[0, :, 6:], det[0, :, :4], (h0, w0)).astype(bool)
+    assert 0.05 < ref.mean() < 0.95
+    for dtype in (torch.uint8, torch.float32):
+        for upsample in ("split", "single"):
+            got, _ = ops.process_mask(dev(proto), dev(det), dev(sm), dev(sb), (h0, w0), n, dtype, upsample=upsample)
+            assert np.array_equal(got.cpu().numpy() != 0, ref), (dtype, upsample, int((got.cpu().numpy().astype(bool) != ref).sum()))
