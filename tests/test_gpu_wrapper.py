@@ -128,6 +128,77 @@ def test_predict_batch_ragged_frames(models):
         assert res['masks'][i].shape == masks.shape and OM.mask_iou(res['masks'][i], masks) >= 0.999
 
 
+def test_predict_batch_eight_ragged_sizes_one_mask_launch(models):
+    """Eight differently sized frames in one batch (the reference's postprocess loops over such a list,
+    model.py:215-236): one NMS + finalize chain and ONE mask launch, checked per image against the oracle."""
+    _, seg = models
+    rng = np.random.default_rng(12)
+    sizes = ((270, 480), (300, 200), (480, 640), (144, 256), (256, 256), (375, 500), (101, 67), (512, 384))
+    frames = [synth.frames_u8(rng, 1, h, w)[0] for h, w in sizes]
+    im, ops = seg.letterbox(frames, (256, 256))
+    y = seg.forward(im)
+    pred, proto = y[0].cpu().numpy(), y[1][-1].cpu().numpy()
+    conf = _conf_for(pred)
+    res, _ = seg.predict_batch(frames, conf, imgsz=(256, 256), max_det=20, _with_index=True)
+    assert len(res['boxes']) >= 6
+    for k, i in enumerate(res['image_index']):
+        boxes, scores, classes, masks = oracle_postprocess(pred[i:i + 1], proto[i], (256, 256), sizes[i], conf, NAMES, 0.4, max_det=20)
+        assert np.abs(res['boxes'][k] - boxes).max() <= 1e-3 and res['classes'][k] == classes
+        assert np.array_equal(res['scores'][k], scores)
+        assert res['masks'][k].shape == masks.shape and res['masks'][k].dtype == np.float32
+        assert OM.mask_iou(res['masks'][k], masks) >= 0.999, i
+    # uint8 masks through the same path
+    seg.mask_dtype = torch.uint8
+    try:
+        res8, _ = seg.predict_batch(frames, conf, imgsz=(256, 256), max_det=20)
+    finally:
+        seg.mask_dtype = torch.float32
+    for a, b in zip(res8['masks'], res['masks']):
+        assert a.dtype == np.uint8 and np.array_equal(a, b.astype(np.uint8))
+
+
+def test_predict_config1_640_det_and_seg(models):
+    """BASELINE config 1: batch 1 at 640x640, conf 0.5-style call with the operator list of the reference's tests
+    (test_yolov8_model.py:84-88: a frame stretched to 640x640, `{'resize': (640, 640, w, h)}`)."""
+    det, seg = models
+    rng = np.random.default_rng(13)
+    frame = synth.frames_u8(rng, 1, 640, 640)[0]
+    ops = [{'resize': (640, 640, 500, 375)}]
+    det.warmup([640, 640])
+    im = det.preprocess(frame)
+    assert im.shape == (1, 3, 640, 640) and np.array_equal(im.cpu().numpy(), OP.preprocess(frame))
+    pred = det.forward(im).cpu().numpy()
+    assert pred.shape == (1, 8, 8400)
+    conf = _conf_for(pred)
+    out, tinfo = det.predict(frame, conf, operators=ops, iou=0.4)
+    boxes, scores, classes, _ = oracle_postprocess(pred, None, (640, 640), (640, 640), conf, NAMES, 0.4)
+    assert len(boxes) > 0 and np.array_equal(out['boxes'], OG.revert_to_origin(boxes, ops))
+    assert np.array_equal(out['scores'], scores) and out['classes'] == classes
+    y = seg.forward(seg.preprocess(frame))
+    pred, proto = y[0].cpu().numpy(), y[1][-1][0].cpu().numpy()
+    assert pred.shape == (1, 40, 8400) and proto.shape == (32, 160, 160)
+    conf = _conf_for(pred)
+    out, _ = seg.predict(frame, conf, operators=[], iou=0.4, max_det=60, return_segments=False)
+    boxes, scores, classes, masks = oracle_postprocess(pred, proto, (640, 640), (640, 640), conf, NAMES, 0.4, max_det=60)
+    assert len(boxes) > 0 and np.array_equal(out['boxes'], OG.revert_to_origin(boxes, []))
+    assert out['masks'].shape == masks.shape and OM.mask_iou(out['masks'], masks) >= 0.999
+
+
+def test_postprocess_reads_fp16_heads_natively(models):
+    """`fp16=True` models hand postprocess an fp16 head (model.py:68,132): it is read as it is, values promoted in
+    the kernels -- same result as the oracle on the promoted head."""
+    det, _ = models
+    rng = np.random.default_rng(14)
+    head = torch.from_numpy(synth.head(rng, 2, 4, 0, 256, objects=10)).cuda().half()
+    img = torch.empty((2, 3, 256, 256), device="cuda")
+    origs = [np.zeros((270, 480, 3), np.uint8), np.zeros((270, 480, 3), np.uint8)]
+    res = det.postprocess(head, img, origs, 0.3, iou=0.45)
+    ref = head.float().cpu().numpy()
+    for i in range(2):
+        boxes, scores, classes, _ = oracle_postprocess(ref[i:i + 1], None, (256, 256), (270, 480), 0.3, NAMES, 0.45)
+        assert np.array_equal(res['boxes'][i], boxes) and np.array_equal(res['scores'][i], scores) and res['classes'][i] == classes
+
+
 def test_predict_seg_with_operators_reverts_on_device(models):
     """The reference's calling convention (test_yolov8_model.py:84-117): the caller resizes / pads the frame, passes
     the operator list, and predict() brings boxes, masks and segments back to sensor space.  Here the revert runs in
