@@ -122,7 +122,9 @@ int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, 
 
 /* Same, for a batch of equally sized frames stored with a constant image stride: no
  * descriptor array, geometry is derived from (h,w,dst_h,dst_w,stretch) on the host; one table
- * set: workspace >= lmi_letterbox_workspace_bytes(1, dst_h, dst_w). */
+ * set: workspace >= lmi_letterbox_workspace_bytes(1, dst_h, dst_w).  mode must be LMI_RESIZE_CV2_LINEAR: the
+ * geometry derived here is cv2's / ultralytics' (round(), centred pad), not the reference helpers' (int()
+ * truncation) that the torch flavours go with -- those take lmi_letterbox_u8 (LMI_ERR_BAD_ARG otherwise). */
 int lmi_letterbox_u8_uniform(const void *src, int batch, int h, int w, int64_t row_stride,
                              int64_t image_stride, void *dst, int dst_h, int dst_w,
                              int dst_dtype, int pad_value, int swap_rb, int stretch, int mode,

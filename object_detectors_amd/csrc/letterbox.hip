@@ -590,6 +590,11 @@ int lmi_letterbox_u8_uniform(const void *src, int batch, int h, int w, int64_t r
                              int mode, void *workspace, int64_t workspace_bytes, void *stream) {
   int rc = check_common(dst, dst_h, dst_w, dst_dtype, pad_value, mode, batch);
   if (rc) return rc;
+  // this form derives the geometry itself, by the cv2 / ultralytics rules (round(), centred pad); the reference
+  // helpers behind the torch flavours size and pad differently (int() truncation, pipeline_utils.py:36-39,110-131),
+  // so those go through lmi_letterbox_u8 with the geometry in the frame descriptors
+  LMI_REQUIRE(mode == LMI_RESIZE_CV2_LINEAR, LMI_ERR_BAD_ARG,
+              "lmi_letterbox_u8_uniform: mode %d needs the helpers' own geometry: use lmi_letterbox_u8 with frame descriptors", mode);
   int32_t g[6];
   rc = lmi_letterbox_geometry(h, w, dst_h, dst_w, stretch, g);
   if (rc) return rc;
@@ -605,9 +610,6 @@ int lmi_letterbox_u8_uniform(const void *src, int batch, int h, int w, int64_t r
   P.new_w = g[0]; P.new_h = g[1]; P.pad_l = g[2]; P.pad_t = g[4];
   P.dst = dst; P.dst_h = dst_h; P.dst_w = dst_w; P.pad_value = pad_value; P.swap_rb = swap_rb ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  P.torch_one_thread = mode == LMI_RESIZE_TORCH_BILINEAR_1T ? 1 : 0;
-  if (mode != LMI_RESIZE_CV2_LINEAR)
-    return dst_dtype == LMI_F32 ? launch_letterbox_torch<float>(P, batch, s) : launch_letterbox_torch<__half>(P, batch, s);
   const int p128 = lds_pitch_for(w, g[0], 128), p32 = lds_pitch_for(w, g[0], 32);
   return dst_dtype == LMI_F32 ? launch_letterbox<float>(P, batch, 1, p128, p32, workspace, workspace_bytes, s)
                               : launch_letterbox<__half>(P, batch, 1, p128, p32, workspace, workspace_bytes, s);

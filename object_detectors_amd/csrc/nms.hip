@@ -810,7 +810,8 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_rotated(SortNmsParams S
   for (int j = tid; j < n_eff; j += kSortThreads) {
     const float4 bj = box[j];
     const float2 cj = cd[j];
-    bool keep = true;
+    // `ious.triu_(1).max(0) < thr`: the column maximum includes the zeros below the diagonal, so nothing passes thr <= 0
+    bool keep = 0.0f < S.iou_thr;
     for (int i = 0; i < j; ++i) {
       const float4 bi = box[i];
       const float2 ci = cd[i];

@@ -99,6 +99,11 @@ def torch_letterbox_geometry(h: int, w: int, dst_h: int, dst_w: int, resize=None
     return new_w, new_h, pl, pr, pt, pb
 
 
+def _check_lb_out(out, b, dst_h, dst_w, tdt, dev) -> None:
+    if not isinstance(out, torch.Tensor) or tuple(out.shape) != (b, 3, dst_h, dst_w) or out.dtype != tdt or not out.is_contiguous() or out.device != dev:
+        raise ValueError(f"letterbox: `out` must be a contiguous {tdt} tensor of shape {(b, 3, dst_h, dst_w)} on the frames' device")
+
+
 def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple[int, int], pad_value: int = 114,
               swap_rb: bool = False, fp16: bool = False, stretch: bool = False,
               out: Optional[torch.Tensor] = None, mode: str = "cv2", resize=None, torch_threads: Optional[int] = None):
@@ -132,10 +137,12 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
         if frames.stride(3) != 1 or frames.stride(2) != 3 or (frames.shape[0] > 1 and frames.stride(0) % 16) or frames.data_ptr() % 16:
             frames = frames.contiguous()
             if frames.shape[0] > 1 and frames.stride(0) % 16:
-                return letterbox(list(frames.unbind(0)), dst_hw, pad_value, swap_rb, fp16, stretch, out)
+                return letterbox(list(frames.unbind(0)), dst_hw, pad_value, swap_rb, fp16, stretch, out, mode)
         b, h, w, _ = frames.shape
         if out is None:
             out = torch.empty((b, 3, dst_h, dst_w), dtype=tdt, device=frames.device)
+        else:
+            _check_lb_out(out, b, dst_h, dst_w, tdt, frames.device)
         ws = _ws.get(frames.device, "letterbox", int(_L.lmi_letterbox_workspace_bytes(1, dst_h, dst_w)))
         check(_L.lmi_letterbox_u8_uniform(frames.data_ptr(), b, h, w, frames.stride(1), frames.stride(0), out.data_ptr(),
                                           dst_h, dst_w, ldt, pad_value, int(swap_rb), int(stretch), 0, ws.data_ptr(),
@@ -170,6 +177,8 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
     ddev = host.to(dev)
     if out is None:
         out = torch.empty((len(keep), 3, dst_h, dst_w), dtype=tdt, device=dev)
+    else:
+        _check_lb_out(out, len(keep), dst_h, dst_w, tdt, dev)
     ws = _ws.get(dev, "letterbox", int(_L.lmi_letterbox_workspace_bytes(len(keep), dst_h, dst_w)))
     check(_L.lmi_letterbox_u8(C.addressof(desc), ddev.data_ptr(), len(keep), out.data_ptr(), dst_h, dst_w, ldt,
                               pad_value, int(swap_rb), (2 if torch_threads == 1 else 1) if mode == "torch" else 0, ws.data_ptr(), ws.numel(), _stream(dev)))

@@ -2,9 +2,18 @@
 
 The file-in / file-out loop of the reference's runner `object_detectors/yolov8_lmi/run_model.py:72-183`
 (same arguments: -w -i -o --sz -c --csv --obb --pose), restricted to what belongs to the accelerated path: the
-frames of a batch are decoded on the host (PIL; the reference uses cv2.imread), uploaded once, letterboxed on the
-GPU in one launch, and boxes / segments come back in each frame's own pixel space.  Drawing annotated images
-(cv2 text and line rendering, run_model.py:122-151,177) is visualisation and is not done here.
+frames of a batch are decoded on the host (PIL; the reference uses cv2.imread), uploaded once and resized on the
+GPU in one launch.  Drawing annotated images (cv2 text and line rendering, run_model.py:122-151,177) is
+visualisation and is not done here.
+
+Geometry.  `--geometry stretch` (the default) is the reference runner's own: every frame is STRETCHED to --sz with
+cv2.resize INTER_LINEAR (run_model.py:83-86; here the same fixed-point arithmetic in the letterbox kernel with
+stretch=True), post-processing runs against the stretched frame (:93), and boxes / segments are un-stretched with
+`/= rw`, `/= rh` in fp32 and truncated by `astype(int32)` (:115-135).  `--geometry letterbox` is this build's
+additive path: aspect-preserving resize + centred pad 114, boxes / masks / segments come back in each frame's own
+pixel space through `scale_boxes` -- for frames whose aspect ratio differs from --sz the network then sees a
+different input than in the reference runner, so preds.csv differs from the reference's (it is the same only when
+the frames already have the size --sz).
 
 preds.csv has the reference's format (`lmi_utils/label_utils/csv_utils.py:108-135`): `;`-separated rows
 `file;class;confidence;rect;upper left;x;y;angle;a` + `...;lower right;...` for a detection without a mask and
@@ -77,9 +86,50 @@ def write_rows(rows: List[list], filename: str):
         csv.writer(f, delimiter=';').writerows(rows)
 
 
-def run(model, path_imgs: str, path_out: str, sz, confidence=0.25, save_csv=True, batch_size=16) -> Dict[str, float]:
+class _ShapeOnly:
+    """Stands for the stretched frame that the reference hands to postprocess (run_model.py:93): only its shape is read."""
+
+    def __init__(self, h, w):
+        self.shape = (int(h), int(w), 3)
+
+
+def unstretch(points: np.ndarray, rw: float, rh: float) -> np.ndarray:
+    """`box[[0,2]] /= rw; box[[1,3]] /= rh` / `seg[:,0] /= rw; seg[:,1] /= rh` (run_model.py:119-120,133-134): an fp32
+    array divided in place by a Python float, i.e. by the ratio rounded to fp32.  points (..., 2k) as x,y,x,y..."""
+    out = np.array(points, dtype=np.float32, copy=True)
+    out[..., 0::2] /= np.float32(rw)
+    out[..., 1::2] /= np.float32(rh)
+    return out
+
+
+def predict_stretched(model, frames, confidence, sz):
+    """The reference runner's geometry for a batch: stretch -> forward -> postprocess against the stretched frames ->
+    un-stretch.  Returns (results with 'image_index', time_info)."""
+    import torch
+    ti = {}
+    t0 = time.time()
+    im, _ = model.letterbox(frames, tuple(sz), stretch=True)
+    ti['preproc'] = time.time() - t0
+    t0 = time.time()
+    pred = model.forward(im)
+    ti['proc'] = time.time() - t0
+    t0 = time.time()
+    stretched = [_ShapeOnly(sz[0], sz[1]) for _ in frames]
+    results = model.postprocess(pred, im, stretched, confidence, return_segments=True, _with_index=True)
+    for r, i in enumerate(results['image_index']):
+        rh, rw = sz[0] / frames[i].shape[0], sz[1] / frames[i].shape[1]
+        results['boxes'][r] = unstretch(results['boxes'][r], rw, rh)
+        if 'segments' in results and len(results['segments']):
+            results['segments'][r] = [unstretch(np.asarray(s), rw, rh) if len(s) else s for s in results['segments'][r]]
+    ti['postproc'] = time.time() - t0
+    return results, ti
+
+
+def run(model, path_imgs: str, path_out: str, sz, confidence=0.25, save_csv=True, batch_size=16, geometry='stretch') -> Dict[str, float]:
     """Process every image under path_imgs; returns the timing summary (also written to summary.json)."""
     import torch
+    if geometry not in ('stretch', 'letterbox'):
+        raise ValueError(f'unknown geometry {geometry!r}')
     os.makedirs(path_out, exist_ok=True)
     t0 = time.time()
     model.warmup(list(sz))
@@ -92,7 +142,10 @@ def run(model, path_imgs: str, path_out: str, sz, confidence=0.25, save_csv=True
         t0 = time.time()
         frames = [load_rgb(p) for p in batch]
         t['decode'] += time.time() - t0
-        results, ti = model.predict_batch(frames, confidence, imgsz=tuple(sz), return_segments=True, _with_index=True)
+        if geometry == 'stretch':
+            results, ti = predict_stretched(model, frames, confidence, sz)
+        else:
+            results, ti = model.predict_batch(frames, confidence, imgsz=tuple(sz), return_segments=True, _with_index=True)
         torch.cuda.synchronize()
         for k in ('preproc', 'proc', 'postproc'):
             t[k] += ti[k]
@@ -109,7 +162,7 @@ def run(model, path_imgs: str, path_out: str, sz, confidence=0.25, save_csv=True
     if save_csv:
         write_rows(rows, os.path.join(path_out, 'preds.csv'))
     summary = {'images': n_img, 'detections': n_det, 'wall_s': round(wall, 4), 'images_per_s': round(n_img / wall, 2) if wall > 0 else 0.0,
-               'batch_size': batch_size, **{f'{k}_s': round(v, 4) for k, v in t.items()}}
+               'batch_size': batch_size, 'geometry': geometry, **{f'{k}_s': round(v, 4) for k, v in t.items()}}
     with open(os.path.join(path_out, 'summary.json'), 'w') as f:
         json.dump(summary, f, indent=1)
     return summary
@@ -126,6 +179,8 @@ def main(argv=None):
     ap.add_argument('--obb', action='store_true')
     ap.add_argument('--pose', action='store_true')
     ap.add_argument('--batch', default=16, type=int, help='frames per launch (the reference runs one at a time)')
+    ap.add_argument('--geometry', default='stretch', choices=['stretch', 'letterbox'],
+                    help="stretch: the reference runner's cv2.resize warp and /rw,/rh un-warp (default); letterbox: aspect-preserving")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO)
     if args.obb or args.pose:
@@ -137,7 +192,7 @@ def main(argv=None):
         sys.path.insert(0, dropin)
     from yolov8_lmi.model import Yolov8
     model = Yolov8(args.wts_file)
-    s = run(model, args.path_imgs, args.path_out, args.sz, args.confidence, args.csv, args.batch)
+    s = run(model, args.path_imgs, args.path_out, args.sz, args.confidence, args.csv, args.batch, args.geometry)
     print(json.dumps(s))
     return 0
 

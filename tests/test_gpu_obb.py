@@ -74,6 +74,9 @@ def test_rotated_nms_not_greedy_and_errors():
     assert count.item() == 1 and anchor[0, 0].item() == 0
     det, count, anchor = ops.nms_v8(torch.from_numpy(p).cuda(), 0.5, 0.999999, nc=1, rotated=True)
     assert count.item() == 3 and anchor[0, :3].tolist() == [0, 1, 2]
+    # threshold 0: `ious.triu_(1).max(0) < 0` holds for nobody, not even the top candidate (the oracle agrees)
+    det, count, anchor = ops.nms_v8(torch.from_numpy(p).cuda(), 0.5, 0.0, nc=1, rotated=True)
+    assert count.item() == 0 and len(OO.nms_rotated(boxes, np.array([0.9, 0.8, 0.7], F32), 0.0)[0]) == 0
     with pytest.raises(ValueError):
         ops.nms_v8(torch.zeros((1, 5, 64), device="cuda"), 0.5, 0.45, nc=1, rotated=True)   # no angle channel
 

@@ -17,7 +17,7 @@ DROPIN = os.path.join(ROOT, "object_detectors_amd", "dropin")
 if DROPIN not in sys.path:
     sys.path.insert(0, DROPIN)
 
-from oracle import boxes as OB, geometry as OG, masks as OM, nms as ON, preprocess as OP  # noqa: E402
+from oracle import boxes as OB, cv2_resize as OC, geometry as OG, masks as OM, nms as ON, preprocess as OP  # noqa: E402
 from object_detectors_amd import synth  # noqa: E402
 from object_detectors_amd.nets.yolov8 import YoloV8  # noqa: E402
 
@@ -287,7 +287,7 @@ def test_folder_harness_writes_the_reference_csv(models, tmp_path):
         im, _ = model.letterbox([run_folder.load_rgb(str(src / f"f{i:02d}.png")) for i in range(5)], (256, 256))
         y = model.forward(im)
         conf = min(_conf_for((y[0] if isinstance(y, (list, tuple)) else y)[i:i + 1].cpu().numpy()) for i in range(5))
-        s = run_folder.run(model, str(src), str(out), (256, 256), conf, True, batch_size=2)
+        s = run_folder.run(model, str(src), str(out), (256, 256), conf, True, batch_size=2, geometry="letterbox")
         assert s["images"] == 5 and s["images_per_s"] > 0 and os.path.isfile(out / "summary.json")
         rows = list(_csv.reader(open(out / "preds.csv"), delimiter=";"))
         want = []
@@ -304,3 +304,24 @@ def test_folder_harness_writes_the_reference_csv(models, tmp_path):
         assert kinds == ({"polygon"} if tag == "seg" else {"rect"})
         if tag == "det":
             assert rows[0][4] == "upper left" and rows[1][4] == "lower right" and rows[0][7] == "angle" and rows[0][8] == "0.00"
+    # the reference runner's own geometry (the default): stretch to --sz, post-process against the stretched frame,
+    # un-stretch with /rw, /rh in fp32, truncate (run_model.py:83-93,115-121) -- rebuilt here from the oracle's pieces
+    out = tmp_path / "stretch"
+    frames = [run_folder.load_rgb(str(src / f"f{i:02d}.png")) for i in range(5)]
+    im, _ = det.letterbox(frames, (256, 256), stretch=True)
+    for i, f in enumerate(frames):
+        assert np.array_equal(im[i].cpu().numpy(), OP.preprocess(OC.resize_linear_u8(f, 256, 256))[0])
+    pred = det.forward(im).cpu().numpy()
+    conf = min(_conf_for(pred[i:i + 1]) for i in range(5))
+    s = run_folder.run(det, str(src), str(out), (256, 256), conf, True, batch_size=3)
+    assert s["geometry"] == "stretch"
+    rows = list(_csv.reader(open(out / "preds.csv"), delimiter=";"))
+    want = []
+    for i, f in enumerate(frames):
+        boxes, scores, classes, _ = oracle_postprocess(pred[i:i + 1], None, (256, 256), (256, 256), conf, NAMES, 0.45)
+        rh, rw = 256 / f.shape[0], 256 / f.shape[1]
+        b = boxes.copy()
+        b[:, [0, 2]] /= rw
+        b[:, [1, 3]] /= rh
+        want += run_folder.result_rows(f"f{i:02d}.png", b, scores, classes, None)
+    assert len(want) > 0 and rows == [[str(v) for v in r] for r in want]
