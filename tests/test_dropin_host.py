@@ -88,14 +88,18 @@ def test_result_dict_assembly_matches_reference_layout(weights):
     keep_h = np.zeros((3, 5), bool)
     keep_h[0, [0, 2]] = True            # the middle detection failed its per-class threshold
     origs = [np.zeros((8, 8, 3), np.uint8)] * 3
-    r = m._assemble(torch.from_numpy(det_h), det_h, count_h, keep_h, [None] * 3, origs, False, False)
+    r = m._assemble(None, None, det_h, count_h, keep_h, [None] * 3, origs, False, False)
     # image 1 had no NMS survivor: it contributes NO entry (model.py:219-220); image 2 has one row, filtered out
     assert len(r['boxes']) == 2 and set(r) == {'boxes', 'scores', 'classes'}
     assert isinstance(r['boxes'][0], np.ndarray) and r['boxes'][0].tolist() == [[1, 2, 3, 4], [9, 10, 11, 12]]
     assert r['classes'][0] == ['c0', 'c5'] and r['scores'][0].tolist() == [np.float32(0.9), np.float32(0.4)]
     assert r['boxes'][1].shape == (0, 4) and r['classes'][1] == []
-    rt = m._assemble(torch.from_numpy(det_h), det_h, count_h, keep_h, [None] * 3, [torch.zeros(8, 8, 3)] * 3, False, False)
+    # tensor originals: per-image views of ONE gather of the survivors' rows (dense slot order) -- here built by hand
+    kept = torch.from_numpy(np.concatenate([det_h[b, :count_h[b]][keep_h[b, :count_h[b]]] for b in range(3)]))
+    rows_dev, slot_base = (kept[:, :4].contiguous(), kept[:, 4].contiguous()), np.array([0, 2, 2, 2])
+    rt = m._assemble(rows_dev, slot_base, det_h, count_h, keep_h, [None] * 3, [torch.zeros(8, 8, 3)] * 3, False, False)
     assert isinstance(rt['boxes'][0], torch.Tensor) and isinstance(rt['classes'][0], list)
+    assert rt['boxes'][0].tolist() == [[1, 2, 3, 4], [9, 10, 11, 12]] and rt['boxes'][1].shape == (0, 4) and rt['classes'][0] == ['c0', 'c5']
 
 
 def test_pipeline_utils_matches_reference_fixtures(golden_dir):
