@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr int TH = 8;  // output rows per tile
+constexpr int kTH = 8;  // output rows per tile of the default shape
 
 struct LbParams {
   const lmi_frame *frames;  // [device] ragged batch, or nullptr for the uniform form below
@@ -156,7 +156,7 @@ struct OutTraits<__half> {
 
 // Workgroup = (TW/4) x TH lanes; lane (g, r) produces output pixels x = tile_x0 + 4g .. +3 of
 // row tile_y0 + r.  LDS holds only the staged source rows.
-template <typename OutT, int TW>
+template <typename OutT, int TW, int TH>
 __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
   constexpr int NT = (TW / 4) * TH;
   extern __shared__ __attribute__((aligned(16))) unsigned char rows[];
@@ -473,7 +473,7 @@ int lds_pitch_for(int w, int new_w, int tw) {
   return (int)((bytes + 15) & ~15L);
 }
 
-size_t lds_bytes_for(int pitch) { return (size_t)2 * TH * pitch; }
+size_t lds_bytes_for(int pitch, int th = kTH) { return (size_t)2 * th * pitch; }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -509,16 +509,16 @@ int launch_letterbox(const LbParams &P0, int batch, int sets, int max_pitch128, 
   if (lds_bytes_for(max_pitch128) <= kMaxLds) {
     P.pitch = max_pitch128;
     P.tiles_x = (P.dst_w + 127) / 128;
-    P.tiles_y = (P.dst_h + TH - 1) / TH;
+    P.tiles_y = (P.dst_h + kTH - 1) / kTH;
     dim3 grid(P.tiles_x * P.tiles_y, batch);
-    hipLaunchKernelGGL((letterbox_kernel<OutT, 128>), grid, dim3(32 * TH), lds_bytes_for(P.pitch), stream, P);
+    hipLaunchKernelGGL((letterbox_kernel<OutT, 128, kTH>), grid, dim3(32 * kTH), lds_bytes_for(P.pitch), stream, P);
   } else if (lds_bytes_for(max_pitch32) <= 2 * kMaxLds) {
     P.pitch = max_pitch32;
     P.tiles_x = (P.dst_w + 31) / 32;
-    P.tiles_y = (P.dst_h + TH - 1) / TH;
+    P.tiles_y = (P.dst_h + kTH - 1) / kTH;
     dim3 grid(P.tiles_x * P.tiles_y, batch);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(letterbox_kernel<OutT, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)kMaxLds);
-    hipLaunchKernelGGL((letterbox_kernel<OutT, 32>), grid, dim3(8 * TH), lds_bytes_for(P.pitch), stream, P);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(letterbox_kernel<OutT, 32, kTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)kMaxLds);
+    hipLaunchKernelGGL((letterbox_kernel<OutT, 32, kTH>), grid, dim3(8 * kTH), lds_bytes_for(P.pitch), stream, P);
   } else {
     lmi_set_error("lmi_letterbox_u8: down-scale factor too large for the LDS row tiles");
     return LMI_ERR_LIMIT;

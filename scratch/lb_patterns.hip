@@ -124,7 +124,12 @@ int main() {
   const size_t out_bytes = (size_t)B * 3 * S * S * 4;
   float *out; CK(hipMalloc(&out, out_bytes));
   const size_t src_bytes = (size_t)B * 2160 * 11520;
-  u4 *src; CK(hipMalloc(&src, src_bytes)); CK(hipMemset(src, 1, src_bytes));
+  constexpr int NSRC = 3;   // rotated between launches: cold reads (the Infinity Cache holds 256 MB)
+  u4 *srcs[NSRC];
+  for (int i = 0; i < NSRC; ++i) { CK(hipMalloc(&srcs[i], src_bytes)); CK(hipMemset(srcs[i], 1 + i, src_bytes)); }
+  int rot = 0;
+  auto next_src = [&]() { rot = (rot + 1) % NSRC; return srcs[rot]; };
+  u4 *src = srcs[0];
   const double MB = out_bytes / 1e6;
   printf("output %.1f MB\n", MB);
   printf("memset: %.1f us\n", run([&] { CK(hipMemsetAsync(out, 0, out_bytes, 0)); }));
@@ -135,21 +140,22 @@ int main() {
     printf("B strip R=16 grid %4d: %.1f us\n", g, run([&] { hipLaunchKernelGGL(fill_strip<16>, dim3(g), dim3(256), 0, 0, out, S / 16); }));
   }
   printf("C tile 128x8 (25600 wg): %.1f us\n", run([&] { hipLaunchKernelGGL(fill_tile, dim3(5 * 80, B), dim3(256), 0, 0, out); }));
+  printf("(sources rotate over %d buffers: cold reads)\n", NSRC);
   struct Cfg { const char *name; int src_rows, row_vec, rows_per_out, step; double rd_mb; } cfgs[] = {
       {"1080p (1 row of 5760 B per content row)", 1080, 360, 1, 3, 64 * 360 * 5760 / 1e6},
       {"4K (2 rows of 11520 B per content row)", 2160, 720, 2, 6, 64 * 360 * 2 * 11520 / 1e6}};
   for (auto &c : cfgs) {
     printf("--- %s: reads %.1f MB + writes %.1f MB\n", c.name, c.rd_mb, MB);
     for (int g : {256, 512, 1024, 2048, 5120}) {
-      float t8 = run([&] { hipLaunchKernelGGL(mix_strip<8>, dim3(g), dim3(256), 0, 0, out, src, c.src_rows, c.row_vec, c.rows_per_out, c.step, S / 8); });
-      float t4 = run([&] { hipLaunchKernelGGL(mix_strip<4>, dim3(std::min(g * 2, 10240)), dim3(256), 0, 0, out, src, c.src_rows, c.row_vec, c.rows_per_out, c.step, S / 4); });
+      float t8 = run([&] { src = next_src(); hipLaunchKernelGGL(mix_strip<8>, dim3(g), dim3(256), 0, 0, out, src, c.src_rows, c.row_vec, c.rows_per_out, c.step, S / 8); });
+      float t4 = run([&] { src = next_src(); hipLaunchKernelGGL(mix_strip<4>, dim3(std::min(g * 2, 10240)), dim3(256), 0, 0, out, src, c.src_rows, c.row_vec, c.rows_per_out, c.step, S / 4); });
       printf("D mix R=8 grid %4d: %.1f us (%.0f GB/s) | R=4 grid x2: %.1f us (%.0f GB/s)\n", g, t8, (c.rd_mb + MB) / t8 * 1e3, t4, (c.rd_mb + MB) / t4 * 1e3);
     }
     for (int g : {256, 512, 1024}) {
       // K loads of 16 B per lane cover R*rows_per_out*row_vec vectors: 1080p R=8: 2880/256 -> 12; 4K R=4: 5760/256 -> 23
       float t = c.rows_per_out == 1
-                    ? run([&] { hipLaunchKernelGGL((mix_strip_pipe<8, 12>), dim3(g), dim3(256), 0, 0, out, src, c.src_rows, c.row_vec, c.rows_per_out, c.step, S / 8); })
-                    : run([&] { hipLaunchKernelGGL((mix_strip_pipe<4, 23>), dim3(g), dim3(256), 0, 0, out, src, c.src_rows, c.row_vec, c.rows_per_out, c.step, S / 4); });
+                    ? run([&] { src = next_src(); hipLaunchKernelGGL((mix_strip_pipe<8, 12>), dim3(g), dim3(256), 0, 0, out, src, c.src_rows, c.row_vec, c.rows_per_out, c.step, S / 8); })
+                    : run([&] { src = next_src(); hipLaunchKernelGGL((mix_strip_pipe<4, 23>), dim3(g), dim3(256), 0, 0, out, src, c.src_rows, c.row_vec, c.rows_per_out, c.step, S / 4); });
       printf("E pipelined grid %4d: %.1f us (%.0f GB/s)\n", g, t, (c.rd_mb + MB) / t * 1e3);
     }
   }
