@@ -9,12 +9,12 @@
 //  nms_decode_filter  grid (anchor tiles, batch): streams the nc class rows of the head once with
 //                     128-bit loads (HBM-bound, nc*A*4 bytes/image), class-max / first-argmax per
 //                     anchor, strict fp32 `> conf`, wave-ballot compaction of (score, anchor) keys.
-//  nms_sort_suppress  one 1024-lane workgroup per image (latency-bound, LDS-resident): bitonic
-//                     sort of the 64-bit keys (score desc, anchor asc = torchvision's stable
-//                     order), then the greedy pass.  Per-class NMS with <= 128 classes and <= 2048
-//                     candidates: decomposed by class (class_parallel_nms: one lane per candidate,
-//                     bit rows of suppressing predecessors, fixpoint rounds, no per-chunk barriers).
-//                     Otherwise (agnostic, many classes, a class of > 256 candidates, ...): 64-candidate
+//  nms_sort_suppress  one 1024-lane workgroup per image (latency-bound, LDS-resident).  Per-class NMS
+//                     with <= 128 classes and <= 2048 candidates: decomposed by class WITHOUT sorting the
+//                     list (class_parallel_nms: one lane per candidate, bit rows of suppressing
+//                     higher-keyed class members, fixpoint rounds; only the kept keys are sorted).
+//                     Otherwise (agnostic, many classes, a class of > 256 candidates, ...): bitonic sort
+//                     of the 64-bit keys (score desc, anchor asc = torchvision's stable order), then 64-candidate
 //                     chunks, every wave tests the chunk against the kept boxes held in LDS, pair masks
 //                     inside the chunk come from wave ballots, the chunk's greedy answer is a fixpoint
 //                     in one wave.  Both stop at max_det keeps.
@@ -193,21 +193,91 @@ __device__ __forceinline__ void bitonic_desc(KeyPtr a, int P2) {
   }
 }
 
-// The same network for keys in LDS with far fewer workgroup barriers: strides shorter than a wave's segment of the
-// array (>= 128 keys) touch that segment only, so the wave that owns it runs all of them back to back -- LDS
-// operations of one wave complete in order, a wavefront-scope fence keeps the compiler from moving them -- and the
-// workgroup meets only around the strides that cross segments: 15 barriers instead of 66 for 2048 keys.
-__device__ __forceinline__ void bitonic_desc_lds(uint64_t *a, int P2) {
+// The same network for keys in LDS with the strides inside a wave's segment done in REGISTERS: a wave owns a segment
+// of 64*KPL keys, lane l holds the keys at segment positions l + 64q.  Strides >= 64 inside the segment pair two
+// registers of one lane; strides < 64 pair lanes l and l ^ j (one cross-lane exchange per key, no LDS write / read
+// round trip, no fence); only strides that cross segments go through LDS, between two workgroup barriers.  For 2048
+// keys: 28 of the 66 steps (stages k <= 128) never touch LDS, 28 more run in registers between the cross-segment
+// steps, 10 steps + 14 barriers remain in LDS.
+template <int KPL>
+__device__ __forceinline__ void bitonic_desc_regs(uint64_t *a, int P2) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int NW = kSortThreads / 64;
-  const int seg = P2 < 128 ? P2 : max(128, P2 / NW);
-  const int nseg = P2 / seg;
-  const int base = wave * seg;
+  constexpr int SEG = 64 * KPL;
+  const int nseg = P2 / SEG;
+  const bool active = wave < nseg;
+  const int base = wave * SEG;
+  uint64_t r[KPL];
+#pragma unroll
+  for (int q = 0; q < KPL; ++q) r[q] = active ? a[base + lane + 64 * q] : 0ull;
   for (int k = 2; k <= P2; k <<= 1) {
     int j = k >> 1;
-    for (; j >= seg; j >>= 1) {   // strides across segments: every lane of the workgroup, then a barrier
-      for (int t = tid; t < (P2 >> 1); t += kSortThreads) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+    if (j >= SEG) {   // uniform: strides across segments, every lane of the workgroup on the LDS copy
+      if (active) {
+#pragma unroll
+        for (int q = 0; q < KPL; ++q) a[base + lane + 64 * q] = r[q];
+      }
+      __syncthreads();
+      for (; j >= SEG; j >>= 1) {
+        for (int t = tid; t < (P2 >> 1); t += kSortThreads) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int p = i | j;
+          const uint64_t x = a[i], y = a[p];
+          const bool desc = (i & k) == 0;
+          if (desc ? (x < y) : (x > y)) { a[i] = y; a[p] = x; }
+        }
+        __syncthreads();
+      }
+      if (active) {
+#pragma unroll
+        for (int q = 0; q < KPL; ++q) r[q] = a[base + lane + 64 * q];
+      }
+    }
+    if (active) {
+      for (; j >= 64; j >>= 1) {   // both keys of a pair live in this lane
+        const int dq = j >> 6;
+#pragma unroll
+        for (int q = 0; q < KPL; ++q) {
+          if ((q & dq) == 0 && (q | dq) < KPL) {
+            const bool desc = ((base + lane + 64 * q) & k) == 0;
+            const uint64_t x = r[q], y = r[q | dq];
+            const uint64_t hi = x > y ? x : y, lo = x > y ? y : x;
+            r[q] = desc ? hi : lo;
+            r[q | dq] = desc ? lo : hi;
+          }
+        }
+      }
+      for (; j > 0; j >>= 1) {     // partner key in lane l ^ j
+        const bool low = (lane & j) == 0;
+#pragma unroll
+        for (int q = 0; q < KPL; ++q) {
+          const uint64_t x = r[q];
+          const uint64_t y = __shfl_xor((unsigned long long)x, j);
+          const bool desc = ((base + lane + 64 * q) & k) == 0;
+          const uint64_t hi = x > y ? x : y, lo = x > y ? y : x;
+          r[q] = (desc == low) ? hi : lo;
+        }
+      }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int q = 0; q < KPL; ++q) a[base + lane + 64 * q] = r[q];
+  }
+  __syncthreads();
+}
+
+// descending sort of P2 (power of two) keys in LDS
+__device__ __forceinline__ void bitonic_desc_lds(uint64_t *a, int P2) {
+  if (P2 >= 128) {
+    if (P2 <= 128 * (kSortThreads / 64)) bitonic_desc_regs<2>(a, P2);
+    else bitonic_desc_regs<4>(a, P2);   // kSortLdsCap = 4096 keys = 16 waves x 256
+    return;
+  }
+  const int tid = threadIdx.x;           // < 128 keys: a handful of steps, one wave's worth of pairs
+  for (int k = 2; k <= P2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (tid < (P2 >> 1)) {
+        const int i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1));
         const int p = i | j;
         const uint64_t x = a[i], y = a[p];
         const bool desc = (i & k) == 0;
@@ -215,21 +285,6 @@ __device__ __forceinline__ void bitonic_desc_lds(uint64_t *a, int P2) {
       }
       __syncthreads();
     }
-    if (wave < nseg) {
-      for (; j > 0; j >>= 1) {    // strides inside this wave's segment
-        for (int t = lane; t < (seg >> 1); t += 64) {
-          const int i = base + (((t & ~(j - 1)) << 1) | (t & (j - 1)));
-          const int p = i | j;
-          const uint64_t x = a[i], y = a[p];
-          const bool desc = (i & k) == 0;
-          if (desc ? (x < y) : (x > y)) { a[i] = y; a[p] = x; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
-    }
-    if (k >= seg) __syncthreads();   // the next stage starts with a stride across segments (or the sort is done)
   }
 }
 
@@ -245,34 +300,40 @@ __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay
 }
 
 // ---------------------------------------------------------------------------------------------
-// Class-parallel suppression.  With per-class NMS the class offset (cls * max_wh) moves the boxes of different
-// classes so far apart that they cannot intersect, PROVIDED the x-extent of all candidates together is below
-// max_wh (checked per image; the fp32 rounding of the offset coordinates is below 0.1 px for <= 128 classes).
-// torchvision's greedy pass over the score-ordered list then decomposes into independent greedy passes per class,
-// each over that class's candidates in the same order and on the same offset coordinates -- identical keeps.
-// So instead of walking the list in 64-candidate chunks with two workgroup barriers each:
-//   1. the candidates are grouped by class (LDS counting pass; the order inside a class does not matter);
-//   2. one lane per candidate j tests j against the members of its class that precede it in the list and keeps
-//      the outcomes as a bit row (classes of <= 256 candidates: up to four 64-bit words per candidate);
+// Class-parallel suppression, WITHOUT sorting the candidates first.  With per-class NMS the class offset
+// (cls * max_wh) moves the boxes of different classes so far apart that they cannot intersect, PROVIDED the x-extent
+// of all candidates together is below max_wh (checked per image; the fp32 rounding of the offset coordinates is
+// below 0.1 px for <= 128 classes).  torchvision's greedy pass over the score-ordered list then decomposes into
+// independent greedy passes per class, each over that class's candidates in the same order and on the same offset
+// coordinates -- identical keeps.  Inside a class only the RELATIVE order of two candidates matters, and that is a
+// comparison of their keys (score, then anchor: torchvision's stable order).  So the 2048-key bitonic sort of the
+// whole list (15 of the 42 us of a dense image) is not needed to decide who is kept:
+//   1. the candidates are grouped by class (LDS counting pass; the order inside a class does not matter) and their
+//      keys and class-offset boxes are written in grouped order;
+//   2. one lane per candidate j tests j against every member of its class with a LARGER key and keeps the outcomes
+//      as a bit row (classes of <= 256 candidates: up to four 64-bit words per candidate);
 //   3. the greedy answer of every class is the fixpoint of  keep_j = no kept predecessor suppresses j,  reached by
-//      rounds over all candidates at once (after t rounds the first t members of every class are final, so at most
-//      64 rounds; in practice the length of the longest suppression chain);
-//   4. the kept flags are compacted in list order.
-// Falls back (returns false, nothing written) when: agnostic, > kCpMaxClasses classes, the extent check fails, a
-// class holds more than 256 candidates, or the LDS scratch -- the unused upper part of the box buffer -- is too small.
+//      rounds over all candidates at once (after t rounds the t best members of every class are final; in practice
+//      the length of the longest suppression chain);
+//   4. the kept candidates' keys are compacted and only THEY are sorted (a few hundred keys at most) for the
+//      score-ordered output and the max_det cut.
+// Falls back (returns false; the key list is untouched) when the extent check fails or a class holds more than 256
+// candidates; the caller does not come here for agnostic NMS, > kCpMaxClasses classes, > 2048 candidates, more
+// candidates than max_nms (that cut needs the global order), or too little LDS.
 constexpr int kCpMaxClasses = 128;
 constexpr int kCpWords = 4;   // 64-bit words of a class's member set: classes of up to 256 candidates
 
 struct CpScratch {
-  int *ccount, *cstart;     // [ncp] candidates per class, first slot of the class in grp
+  int *ccount, *cstart;     // [ncp] candidates per class, first slot of the class in the grouped arrays
   uint64_t *keep_a, *keep_b;  // [ncp][kCpWords] kept members of every class (bit = slot inside the class), two generations
-  int *misc;                // [0] largest class, [1..17] wave totals of the compaction
-  unsigned short *lcls;     // [P2] class of the sorted candidate
-  unsigned short *grp;      // [P2] list positions grouped by class
-  unsigned char *slotof;    // [P2] slot of the sorted candidate inside its class
+  int *misc;                // [0] largest class, [1..17] wave totals of the compaction, [20] extent verdict
+  float *ext;               // [32] per-wave x-extent partials
+  unsigned short *lcls;     // [P2] class of candidate i (list order)
+  unsigned short *gcls;     // [P2] class of grouped candidate g
+  unsigned char *slotof;    // [P2] slot of candidate i inside its class
 };
 
-__device__ __forceinline__ size_t cp_bytes(int P2, int ncp) { return (size_t)ncp * (16 * kCpWords + 8) + 32 * 4 + (size_t)P2 * 5 + 64; }
+__device__ __forceinline__ size_t cp_bytes(int P2, int ncp) { return (size_t)ncp * (16 * kCpWords + 8) + 32 * 4 + 32 * 4 + (size_t)P2 * 5 + 64; }
 
 __device__ __forceinline__ CpScratch cp_carve(unsigned char *base, int P2, int ncp) {
   CpScratch C;
@@ -282,26 +343,37 @@ __device__ __forceinline__ CpScratch cp_carve(unsigned char *base, int P2, int n
   C.ccount = reinterpret_cast<int *>(q); q += (size_t)ncp * 4;
   C.cstart = reinterpret_cast<int *>(q); q += (size_t)ncp * 4;
   C.misc = reinterpret_cast<int *>(q); q += 32 * 4;
+  C.ext = reinterpret_cast<float *>(q); q += 32 * 4;
   C.lcls = reinterpret_cast<unsigned short *>(q); q += (size_t)P2 * 2;
-  C.grp = reinterpret_cast<unsigned short *>(q); q += (size_t)P2 * 2;
+  C.gcls = reinterpret_cast<unsigned short *>(q); q += (size_t)P2 * 2;
   C.slotof = q;
   return C;
 }
 
-// All lanes of the workgroup call this (uniform control flow).  lbox: offset boxes of the n_eff sorted candidates
-// (n_eff <= 2 * kSortThreads); C.lcls filled by the caller.  On success kpos[0..K) holds the kept list positions
-// in order and *sK = K.
-__device__ bool class_parallel_nms(const CpScratch &C, const float4 *lbox, int n_eff, int P2, int nc, int ncp, int max_det,
-                                   float thr, int *kpos, int *sK) {
+// All lanes of the workgroup call this (uniform control flow).  keys[0..n): the image's candidate keys in any order
+// (n <= 2 * kSortThreads); gkey / gbox: room for n grouped keys / boxes.  On success keys[0..K) holds the kept keys
+// in descending order (K = min(kept, max_det)) and *sK = K.
+template <typename InT>
+__device__ bool class_parallel_nms(const CpScratch &C, uint64_t *keys, uint64_t *gkey, float4 *gbox, const InT *pb, const int *cls_b,
+                                   int A, int n, int P2, int ncp, int max_det, float max_wh, float thr, int *sK) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = kSortThreads / 64;
 
-  // 1. group by class
+  // 1. classes, group by class
   if (tid < ncp) C.ccount[tid] = 0;
   __syncthreads();
-  for (int i = tid; i < n_eff; i += kSortThreads) {
-    const int r = atomicAdd(&C.ccount[C.lcls[i]], 1);
-    C.slotof[i] = (unsigned char)min(r, 255);
+  int mycls[2] = {0, 0};
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = tid + kSortThreads * u;
+    if (i < n) {
+      const uint32_t anchor = ~(uint32_t)keys[i];
+      const int c = cls_b[anchor];
+      mycls[u] = c;
+      C.lcls[i] = (unsigned short)c;
+      const int r = atomicAdd(&C.ccount[c], 1);
+      C.slotof[i] = (unsigned char)min(r, 255);
+    }
   }
   __syncthreads();
   if (wave == 0) {   // class starts (ncp <= 128: two classes per lane) and the largest class
@@ -320,26 +392,64 @@ __device__ bool class_parallel_nms(const CpScratch &C, const float4 *lbox, int n
   __syncthreads();
   if (C.misc[0] > 64 * kCpWords) return false;   // uniform
   const int W = (C.misc[0] + 63) >> 6;             // words in use for this image
-  for (int i = tid; i < n_eff; i += kSortThreads) C.grp[C.cstart[C.lcls[i]] + C.slotof[i]] = (unsigned short)i;
+
+  // grouped keys and class-offset boxes; x-extent of the candidates before the offset
+  float lo_x = INFINITY, hi_x = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = tid + kSortThreads * u;
+    if (i < n) {
+      const uint64_t key = keys[i];
+      const uint32_t anchor = ~(uint32_t)key;
+      const int c = mycls[u];
+      const int g = C.cstart[c] + C.slotof[i];
+      const float cx = ldf(pb, anchor), cy = ldf(pb, (size_t)A + anchor), w = ldf(pb, (size_t)2 * A + anchor), h = ldf(pb, (size_t)3 * A + anchor);
+      const float hw = w / 2.0f, hh = h / 2.0f;
+      const float off = (float)c * max_wh;
+      gkey[g] = key;
+      gbox[g] = make_float4((cx - hw) + off, (cy - hh) + off, (cx + hw) + off, (cy + hh) + off);
+      C.gcls[g] = (unsigned short)c;
+      // NaN coordinates must fail the extent test below: fminf / fmaxf would drop them
+      lo_x = (cx - hw) < lo_x ? (cx - hw) : ((cx - hw) >= lo_x ? lo_x : NAN);
+      hi_x = (cx + hw) > hi_x ? (cx + hw) : ((cx + hw) <= hi_x ? hi_x : NAN);
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const float l2 = __shfl_xor(lo_x, d), h2 = __shfl_xor(hi_x, d);
+    lo_x = (l2 < lo_x) ? l2 : ((l2 >= lo_x) ? lo_x : NAN);
+    hi_x = (h2 > hi_x) ? h2 : ((h2 <= hi_x) ? hi_x : NAN);
+  }
+  if (lane == 0) { C.ext[wave] = lo_x; C.ext[16 + wave] = hi_x; }
   for (int e = tid; e < ncp * kCpWords; e += kSortThreads) {
     const int m = C.ccount[e / kCpWords] - 64 * (e % kCpWords);   // members in this word
     C.keep_a[e] = m >= 64 ? ~0ull : (m > 0 ? ((1ull << m) - 1ull) : 0ull);   // generation 0: everybody
     C.keep_b[e] = 0ull;
   }
   __syncthreads();
+  {
+    float lo = C.ext[0], hi = C.ext[16];
+    for (int w = 1; w < NW; ++w) {
+      const float l2 = C.ext[w], h2 = C.ext[16 + w];
+      lo = (l2 < lo) ? l2 : ((l2 >= lo) ? lo : NAN);
+      hi = (h2 > hi) ? h2 : ((h2 <= hi) ? hi : NAN);
+    }
+    // boxes of different classes cannot intersect when every candidate lies inside one max_wh-wide band
+    if (!((hi - lo) <= max_wh - 1.0f)) return false;   // uniform; false for NaN.  keys[0..n) are untouched
+  }
 
   // 2. one lane per candidate, in class-grouped order (the lanes of a wave walk classes of similar length and read
-  //    the same members: LDS broadcasts): bit r = member r of my class precedes me in the list and would suppress me
+  //    the same members: LDS broadcasts): bit r = member r of my class has a larger key and would suppress me
   uint64_t bits[2][kCpWords] = {};
   int myc[2] = {0, 0}, myslot[2] = {0, 0};
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int g = tid + kSortThreads * u;
-    if (g >= n_eff) break;
-    const int j = C.grp[g];
-    const int c = C.lcls[j], sc = C.cstart[c], mc = C.ccount[c];
+    if (g >= n) break;
+    const int c = C.gcls[g], sc = C.cstart[c], mc = C.ccount[c];
     myc[u] = c; myslot[u] = g - sc;
-    const float4 cb = lbox[j];
+    const uint64_t mykey = gkey[g];
+    const float4 cb = gbox[g];
     const float carea = (cb.z - cb.x) * (cb.w - cb.y);
 #pragma unroll
     for (int w = 0; w < kCpWords; ++w) {
@@ -347,11 +457,9 @@ __device__ bool class_parallel_nms(const CpScratch &C, const float4 *lbox, int n
       uint64_t bset = 0ull;
       const int r1 = min(64, mc - 64 * w);
       for (int r = 0; r < r1; ++r) {
-        const int pr = C.grp[sc + 64 * w + r];
-        if (pr < j) {
-          const float4 kb = lbox[pr];
-          if (iou_gt(kb.x, kb.y, kb.z, kb.w, (kb.z - kb.x) * (kb.w - kb.y), cb.x, cb.y, cb.z, cb.w, carea, thr)) bset |= 1ull << r;
-        }
+        const uint64_t kr = gkey[sc + 64 * w + r];
+        const float4 kb = gbox[sc + 64 * w + r];
+        if (kr > mykey && iou_gt(kb.x, kb.y, kb.z, kb.w, (kb.z - kb.x) * (kb.w - kb.y), cb.x, cb.y, cb.z, cb.w, carea, thr)) bset |= 1ull << r;
       }
       bits[u][w] = bset;
     }
@@ -363,7 +471,7 @@ __device__ bool class_parallel_nms(const CpScratch &C, const float4 *lbox, int n
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int g = tid + kSortThreads * u;
-      if (g < n_eff) {
+      if (g < n) {
         uint64_t suppressed = 0ull;
 #pragma unroll
         for (int w = 0; w < kCpWords; ++w)
@@ -384,12 +492,19 @@ __device__ bool class_parallel_nms(const CpScratch &C, const float4 *lbox, int n
   }
   // cur = the kept members of every class
 
-  // 4. compaction in list order: thread t owns positions [per * t, per * t + per)
-  const int per = (P2 + kSortThreads - 1) / kSortThreads;
+  // 4. the kept keys, compacted into keys[0..Kt) (the list itself is no longer needed: gkey holds every key), then
+  //    sorted: the output order and the max_det cut
+  bool kept[2];
   int mine = 0;
-  for (int u = 0; u < per; ++u) {
-    const int i = per * tid + u;
-    if (i < n_eff) mine += (int)((cur[C.lcls[i] * kCpWords + (C.slotof[i] >> 6)] >> (C.slotof[i] & 63)) & 1ull);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int g = 2 * tid + u;   // thread t owns grouped positions 2t, 2t + 1
+    kept[u] = false;
+    if (g < n) {
+      const int c = C.gcls[g], sl = g - C.cstart[c];
+      kept[u] = (cur[c * kCpWords + (sl >> 6)] >> (sl & 63)) & 1ull;
+    }
+    mine += kept[u] ? 1 : 0;
   }
   int incl = mine;
 #pragma unroll
@@ -406,13 +521,13 @@ __device__ bool class_parallel_nms(const CpScratch &C, const float4 *lbox, int n
     total += v;
   }
   int idx = before + incl - mine;
-  for (int u = 0; u < per; ++u) {
-    const int i = per * tid + u;
-    if (i < n_eff && ((cur[C.lcls[i] * kCpWords + (C.slotof[i] >> 6)] >> (C.slotof[i] & 63)) & 1ull)) {
-      if (idx < max_det) kpos[idx] = i;
-      ++idx;
-    }
-  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (kept[u]) keys[idx++] = gkey[2 * tid + u];
+  const int PK = next_pow2(max(total, 1));
+  for (int i = total + tid; i < PK; i += kSortThreads) keys[i] = 0ull;
+  __syncthreads();
+  bitonic_desc_lds(keys, PK);
   if (tid == 0) *sK = min(total, max_det);
   __syncthreads();
   return true;
@@ -546,73 +661,53 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
   const int P2 = next_pow2(n);
   const bool in_lds = P2 <= S.lds_keys;
 
-  // ---- sort -------------------------------------------------------------------------------------
+  // ---- keys into LDS ---------------------------------------------------------------------------------
   if (in_lds) {
     for (int i = tid; i < P2; i += kSortThreads) lkeys[i] = (i < n) ? gkeys[i] : 0ull;
-    __syncthreads();
-    bitonic_desc_lds(lkeys, P2);
-  } else {
-    for (int i = n + tid; i < P2; i += kSortThreads) gkeys[i] = 0ull;
-    __syncthreads();
-    bitonic_desc(gkeys, P2);
-  }
-  const int n_eff = min(n, S.max_nms);
-
-  // ---- decode the sorted candidates' (class-offset) boxes ------------------------------------------
-  // class-parallel suppression (see class_parallel_nms) needs: per-class NMS, few classes, the candidates in LDS
-  // and room for its scratch in the part of the LDS box buffer that this image does not use
-  const int ncp = (S.nc + 1) & ~1;
-  const bool cp_try = in_lds && !S.agnostic && S.nc <= kCpMaxClasses && P2 <= 2 * kSortThreads &&
-                      (size_t)(S.lds_keys - P2) * sizeof(float4) >= cp_bytes(P2, ncp);
-  CpScratch CP{};
-  if (cp_try) CP = cp_carve(reinterpret_cast<unsigned char *>(lbox + P2), P2, ncp);
-  float lo_x = INFINITY, hi_x = -INFINITY;   // x-extent of the candidates before the class offset
-  for (int i = tid; i < n_eff; i += kSortThreads) {
-    const uint64_t key = in_lds ? lkeys[i] : gkeys[i];
-    const uint32_t anchor = ~(uint32_t)key;
-    const float cx = ldf(pb, anchor), cy = ldf(pb, (size_t)A + anchor), w = ldf(pb, (size_t)2 * A + anchor), h = ldf(pb, (size_t)3 * A + anchor);
-    const float hw = w / 2.0f, hh = h / 2.0f;
-    const int cls = S.agnostic ? 0 : S.cls_of[(size_t)b * A + anchor];
-    const float c = S.agnostic ? 0.0f : (float)cls * S.max_wh;
-    const float4 bx = make_float4((cx - hw) + c, (cy - hh) + c, (cx + hw) + c, (cy + hh) + c);
-    if (in_lds) lbox[i] = bx; else sbox[i] = bx;
-    if (cp_try) {
-      CP.lcls[i] = (unsigned short)cls;
-      // NaN coordinates must fail the extent test below: fminf / fmaxf would drop them
-      lo_x = (cx - hw) < lo_x ? (cx - hw) : ((cx - hw) >= lo_x ? lo_x : NAN);
-      hi_x = (cx + hw) > hi_x ? (cx + hw) : ((cx + hw) <= hi_x ? hi_x : NAN);
-    }
-  }
-  bool cp_go = false;
-  if (cp_try) {   // uniform
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-      const float l2 = __shfl_xor(lo_x, d), h2 = __shfl_xor(hi_x, d);
-      lo_x = (l2 < lo_x) ? l2 : ((l2 >= lo_x) ? lo_x : NAN);
-      hi_x = (h2 > hi_x) ? h2 : ((h2 <= hi_x) ? hi_x : NAN);
-    }
-    float *part = reinterpret_cast<float *>(supp);   // 64 ints, zeroed again below
-    if (lane == 0) { part[wave] = lo_x; part[16 + wave] = hi_x; }
-    __syncthreads();
-    float lo = part[0], hi = part[16];
-    for (int w = 1; w < kSortThreads / 64; ++w) {
-      const float l2 = part[w], h2 = part[16 + w];
-      lo = (l2 < lo) ? l2 : ((l2 >= lo) ? lo : NAN);
-      hi = (h2 > hi) ? h2 : ((h2 <= hi) ? hi : NAN);
-    }
-    // boxes of different classes cannot intersect when every candidate lies inside one max_wh-wide band
-    cp_go = (hi - lo) <= S.max_wh - 1.0f;   // false for NaN
     __syncthreads();
   }
   if (tid < 64) supp[tid] = 0;
   if (tid == 0) *sK = 0;
   __syncthreads();
 
+  // ---- class-parallel suppression on the UNSORTED candidates (see class_parallel_nms): per-class NMS, few classes,
+  //      every candidate inside the max_nms cut, the candidates in the lower half of the LDS key buffer (the upper
+  //      half takes the grouped copy) and room for the scratch behind the grouped boxes -------------------------------
+  const int ncp = (S.nc + 1) & ~1;
+  const bool cp_try = in_lds && !S.agnostic && S.nc <= kCpMaxClasses && P2 <= 2 * kSortThreads && n <= S.max_nms &&
+                      2 * P2 <= S.lds_keys && (size_t)(S.lds_keys - P2) * sizeof(float4) >= cp_bytes(P2, ncp);
   int K = 0;
   bool done = false;
-  if (cp_go) {
-    done = class_parallel_nms(CP, lbox, n_eff, P2, S.nc, ncp, S.max_det, S.iou_thr, kpos, sK);
-    if (done) K = *sK;
+  if (cp_try) {
+    const CpScratch CP = cp_carve(reinterpret_cast<unsigned char *>(lbox + P2), P2, ncp);
+    done = class_parallel_nms(CP, lkeys, lkeys + P2, lbox, pb, S.cls_of + (size_t)b * A, A, n, P2, ncp, S.max_det, S.max_wh, S.iou_thr, sK);
+    if (done) {
+      K = *sK;
+      for (int t = tid; t < K; t += kSortThreads) kpos[t] = t;   // the kept keys lie sorted at the head of the list
+      __syncthreads();
+    }
+  }
+
+  // ---- otherwise: sort the whole list, decode the sorted candidates' (class-offset) boxes ----------------------------
+  const int n_eff = min(n, S.max_nms);
+  if (!done) {
+    if (in_lds) {
+      bitonic_desc_lds(lkeys, P2);
+    } else {
+      for (int i = n + tid; i < P2; i += kSortThreads) gkeys[i] = 0ull;
+      __syncthreads();
+      bitonic_desc(gkeys, P2);
+    }
+    for (int i = tid; i < n_eff; i += kSortThreads) {
+      const uint64_t key = in_lds ? lkeys[i] : gkeys[i];
+      const uint32_t anchor = ~(uint32_t)key;
+      const float cx = ldf(pb, anchor), cy = ldf(pb, (size_t)A + anchor), w = ldf(pb, (size_t)2 * A + anchor), h = ldf(pb, (size_t)3 * A + anchor);
+      const float hw = w / 2.0f, hh = h / 2.0f;
+      const float c = S.agnostic ? 0.0f : (float)S.cls_of[(size_t)b * A + anchor] * S.max_wh;
+      const float4 bx = make_float4((cx - hw) + c, (cy - hh) + c, (cx + hw) + c, (cy + hh) + c);
+      if (in_lds) lbox[i] = bx; else sbox[i] = bx;
+    }
+    __syncthreads();
   }
 
   // ---- greedy NMS in chunks of 64 sorted candidates (agnostic NMS, many classes, a very large class, boxes
