@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void mask_box_kernel(UpParams U) {
       const taps a = *reinterpret_cast<const taps *>(reinterpret_cast<const char *>(L + (iy - ly_first) * ls) + oa[k]);
       return fmaf(a.x, wx[k].x, a.y * wx[k].y);   // aten: fma(left, w_left, right * w_right)
     };
-    f2 tt[PX];   // {upper, lower} source row, interpolated horizontally
+    f2 tu[PX / 2], tl[PX / 2];   // upper / lower source row, interpolated horizontally; adjacent pixels paired for packed math
     int cur0 = -1, cur1 = -1;
     for (int y = y_first; y < y_last; ++y) {
       int iy0, iy1; float ly0, ly1;
@@ -496,24 +496,29 @@ __global__ __launch_bounds__(256) void mask_box_kernel(UpParams U) {
       if (iy0 != cur0 || iy1 != cur1) {
         if (iy0 == cur1) {
 #pragma unroll
-          for (int k = 0; k < PX; ++k) tt[k].x = tt[k].y;
+          for (int h = 0; h < PX / 2; ++h) tu[h] = tl[h];
         } else {
 #pragma unroll
-          for (int k = 0; k < PX; ++k) tt[k].x = hrow(iy0, k);
+          for (int h = 0; h < PX / 2; ++h) tu[h] = f2{hrow(iy0, 2 * h), hrow(iy0, 2 * h + 1)};
         }
         if (iy1 == iy0) {
 #pragma unroll
-          for (int k = 0; k < PX; ++k) tt[k].y = tt[k].x;
+          for (int h = 0; h < PX / 2; ++h) tl[h] = tu[h];
         } else {
 #pragma unroll
-          for (int k = 0; k < PX; ++k) tt[k].y = hrow(iy1, k);
+          for (int h = 0; h < PX / 2; ++h) tl[h] = f2{hrow(iy1, 2 * h), hrow(iy1, 2 * h + 1)};
         }
         cur0 = iy0; cur1 = iy1;
       }
+      const f2 w0v = {ly0, ly0}, w1v = {ly1, ly1};
       uint32_t bits = 0;
 #pragma unroll
-      for (int k = 0; k < PX; ++k)
-        if (fmaf(tt[k].x, ly0, tt[k].y * ly1) > 0.0f) bits |= 1u << k;
+      for (int h = 0; h < PX / 2; ++h) {
+        // aten: fma(upper, w_upper, lower * w_lower), two pixels per packed instruction (each half rounds like the scalar form)
+        const f2 v = __builtin_elementwise_fma(tu[h], w0v, tl[h] * w1v);
+        if (v.x > 0.0f) bits |= 1u << (2 * h);
+        if (v.y > 0.0f) bits |= 2u << (2 * h);
+      }
       OutT *p = out + (size_t)y * W0 + x0;
       MO::store_vec_nt(p, bits & xmask);
     }
