@@ -112,11 +112,14 @@ def test_letterbox_full_size_closed_forms(ops):
     ref = lut[f[:, 1::3, 1::3, :].long()].permute(0, 3, 1, 2)
     assert torch.equal(out[:, :, 140:500, :], ref)
     assert torch.all(out[:, :, :140] == lut[114]) and torch.all(out[:, :, 500:] == lut[114])
-    g = torch.from_numpy(rng.integers(0, 256, (2, 2160, 3840, 3), dtype=np.uint8)).cuda()
+    # C4's per-step batch at its literal size: 64 4K frames (1.6 GB) in one launch
+    g = torch.randint(0, 256, (64, 2160, 3840, 3), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
     out, _ = ops.letterbox(g, (640, 640), pad_value=0)
-    gi = g.int()
-    box = (gi[:, 2::6, 2::6] + gi[:, 2::6, 3::6] + gi[:, 3::6, 2::6] + gi[:, 3::6, 3::6] + 2) >> 2
-    assert torch.equal(out[:, :, 140:500, :], lut[box.long()].permute(0, 3, 1, 2))
+    for a in range(0, 64, 8):
+        r0, r1 = g[a:a + 8, 2::6].int(), g[a:a + 8, 3::6].int()   # rows 6dy+2 and 6dy+3: the two taps of the x6 reduction
+        box = (r0[:, :, 2::6] + r0[:, :, 3::6] + r1[:, :, 2::6] + r1[:, :, 3::6] + 2) >> 2
+        assert torch.equal(out[a:a + 8, :, 140:500, :], lut[box.long()].permute(0, 3, 1, 2)), a
+    assert torch.all(out[:, :, :140] == 0) and torch.all(out[:, :, 500:] == 0)
 
 
 # ---------------------------------------------------------------- NMS (a4)
