@@ -17,7 +17,7 @@ right after the timed region.  Prints ONE JSON line on rank 0 (see the keys belo
 
 Sturdiness (round 2): the block of K timed steps -- barrier + synchronize, K steps, barrier + synchronize -- is
 repeated `--blocks` times (default 30) and the line reports the MEDIAN block (max over ranks per block first); the
-spread is in `config.block_ms`.  Steps rotate through `--pool` distinct, device-resident input batches (default 2),
+spread is in `config.block_ms`.  Steps rotate through `--pool` distinct, device-resident input batches (default 3: the source rows of two 1080p batches would still fit the 256 MB Infinity Cache),
 each with its own captured graph.  `--images N` switches to the strong-scaling form of BASELINE config 4: N frames
 in all, sharded by `shard.shard_bounds` (N/world per rank, 64 per step), `"scaling": "strong"`.
 """
@@ -186,7 +186,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="seg640", choices=sorted(WORKLOADS))
     ap.add_argument("--blocks", type=int, default=30, help="the block of --steps timed steps is repeated this many times; the median block is reported")
-    ap.add_argument("--pool", type=int, default=2, help="distinct device-resident input batches the steps rotate through")
+    ap.add_argument("--pool", type=int, default=3, help="distinct device-resident input batches the steps rotate through")
     ap.add_argument("--images", type=int, default=0, help="strong scaling: this many frames IN ALL, sharded over the ranks "
                     "(shard.shard_bounds), per-GPU batch per step; --steps is then derived from the shard (BASELINE config 4: "
                     "--workload det640_4k --images 8192)")
