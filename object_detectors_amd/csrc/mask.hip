@@ -358,6 +358,33 @@ struct MaskOut<uint8_t> {
     __builtin_nontemporal_store(v, reinterpret_cast<u4 *>(p));
   }
   static __device__ __forceinline__ void store1(uint8_t *p, bool on) { *p = on ? 1 : 0; }
+  // `v > 0` for 16 interpolated pixels straight into 16 bytes of 0/1 without compares (v_cmp + v_cndmask pairs and
+  // their SGPR hazards were most of the box pass): a float's bits read as a signed integer are positive for exactly
+  // the values > 0, denormals included, and zero or negative for +-0 and everything below; v_med3_i32 clamps that to
+  // 0..1 and v_lshl_or assembles the bytes.  (A NaN with a clear sign bit would read as 1: the caller keeps NaNs out
+  // of the interpolated rows, see hrow in mask_box_kernel.)  allow: bit k = pixel k lies inside the box's columns.
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ uint32_t pos01(float v) {
+    uint32_t r;
+    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(r) : "v"(v));
+    return r;
+  }
+  static __device__ __forceinline__ void emit_nt(uint8_t *p, const f2v (&v)[8], uint32_t allow) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    uint32_t w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t d = pos01(v[2 * q].x);
+      d |= pos01(v[2 * q].y) << 8;
+      d |= pos01(v[2 * q + 1].x) << 16;
+      d |= pos01(v[2 * q + 1].y) << 24;
+      const uint32_t n = (allow >> (4 * q)) & 0xfu;
+      const uint32_t m = (n & 1u) | ((n & 2u) << 7) | ((n & 4u) << 14) | ((n & 8u) << 21);   // loop-invariant: hoisted out of the row loop
+      w[q] = d & m;
+    }
+    u4 o = {w[0], w[1], w[2], w[3]};
+    __builtin_nontemporal_store(o, reinterpret_cast<u4 *>(p));
+  }
 };
 template <>
 struct MaskOut<float> {
@@ -371,6 +398,15 @@ struct MaskOut<float> {
     __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
   }
   static __device__ __forceinline__ void store1(float *p, bool on) { *p = on ? 1.0f : 0.0f; }
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ void emit_nt(float *p, const f2v (&v)[2], uint32_t allow) {
+    uint32_t bits = 0;
+    if (v[0].x > 0.0f) bits |= 1u;
+    if (v[0].y > 0.0f) bits |= 2u;
+    if (v[1].x > 0.0f) bits |= 4u;
+    if (v[1].y > 0.0f) bits |= 8u;
+    store_vec_nt(p, bits & allow);
+  }
 };
 
 // one record per live slot {xa, xb, ya, yb}: lets mask_box_kernel decide with one load whether a strip has work.
@@ -486,7 +522,9 @@ __global__ __launch_bounds__(256) void mask_box_kernel(UpParams U) {
     // registers across the consecutive output rows that share a source row pair (6-7 rows at 1080p from 160x160)
     auto hrow = [&](int iy, int k) -> float {
       const taps a = *reinterpret_cast<const taps *>(reinterpret_cast<const char *>(L + (iy - ly_first) * ls) + oa[k]);
-      return fmaf(a.x, wx[k].x, a.y * wx[k].y);   // aten: fma(left, w_left, right * w_right)
+      // aten: fma(left, w_left, right * w_right).  fmaxf drops a NaN (non-finite prototypes or coefficients) for a
+      // negative number: `NaN > 0` is false in the reference too, and the byte assembly below reads float bits as integers
+      return fmaxf(fmaf(a.x, wx[k].x, a.y * wx[k].y), -3.0e38f);
     };
     f2 tu[PX / 2], tl[PX / 2];   // upper / lower source row, interpolated horizontally; adjacent pixels paired for packed math
     int cur0 = -1, cur1 = -1;
@@ -511,16 +549,11 @@ __global__ __launch_bounds__(256) void mask_box_kernel(UpParams U) {
         cur0 = iy0; cur1 = iy1;
       }
       const f2 w0v = {ly0, ly0}, w1v = {ly1, ly1};
-      uint32_t bits = 0;
+      f2 v[PX / 2];
 #pragma unroll
-      for (int h = 0; h < PX / 2; ++h) {
-        // aten: fma(upper, w_upper, lower * w_lower), two pixels per packed instruction (each half rounds like the scalar form)
-        const f2 v = __builtin_elementwise_fma(tu[h], w0v, tl[h] * w1v);
-        if (v.x > 0.0f) bits |= 1u << (2 * h);
-        if (v.y > 0.0f) bits |= 2u << (2 * h);
-      }
-      OutT *p = out + (size_t)y * W0 + x0;
-      MO::store_vec_nt(p, bits & xmask);
+      for (int h = 0; h < PX / 2; ++h)   // aten: fma(upper, w_upper, lower * w_lower), two pixels per packed instruction (each half rounds like the scalar form)
+        v[h] = __builtin_elementwise_fma(tu[h], w0v, tl[h] * w1v);
+      MO::emit_nt(out + (size_t)y * W0 + x0, v, xmask);
     }
   }
 }
