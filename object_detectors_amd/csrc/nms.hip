@@ -72,6 +72,8 @@ __device__ __forceinline__ void ld4(const __half *p, float e[4]) {
 struct NmsLayout {
   size_t off_count, off_keys, off_cls, off_sbox, off_cd, total;
   int P;
+  int seg;    // anchors per workgroup of the candidate filter = length of its key segment (256, or 64 for odd anchor counts)
+  int nblk;   // workgroups (segments) per image
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -79,8 +81,11 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 NmsLayout nms_layout(int batch, int anchors) {
   NmsLayout L;
   L.P = next_pow2(anchors);
+  L.seg = (anchors & 3) == 0 ? 256 : 64;
+  L.nblk = (anchors + L.seg - 1) / L.seg;
   size_t o = 0;
-  L.off_count = o; o = align_up(o + sizeof(int) * (size_t)batch, 256);
+  // one candidate count per filter workgroup, written unconditionally by every call: nothing has to be cleared
+  L.off_count = o; o = align_up(o + sizeof(int) * (size_t)batch * L.nblk, 256);
   L.off_keys = o;  o = align_up(o + sizeof(uint64_t) * (size_t)batch * L.P, 256);
   L.off_cls = o;   o = align_up(o + sizeof(int) * (size_t)batch * anchors, 256);
   L.off_sbox = o;  o = align_up(o + sizeof(float4) * (size_t)batch * anchors, 256);
@@ -92,11 +97,13 @@ NmsLayout nms_layout(int batch, int anchors) {
 // ---------------------------------------------------------------------------------------------
 // Workgroup = 4 waves over the SAME 64*VEC anchors; wave w scans one quarter of the class rows (4x the loads in
 // flight of a one-wave-per-anchor-group layout), wave 0 merges the quarters in class order (strict >, so the
-// first maximal class wins as in torch.max) and compacts the candidates.
+// first maximal class wins as in torch.max) and compacts the candidates to the head of the workgroup's OWN key segment
+// (64*VEC keys), in anchor order, and writes their number -- zero included -- to the workgroup's own counter: no
+// atomics, no counter to clear before the launch, and a candidate order that does not change from run to run.
 template <int VEC, typename InT>
 __global__ __launch_bounds__(256) void nms_decode_filter(const InT *__restrict__ pred, int nc, int nm, int A, float conf,
                                                         uint64_t *__restrict__ keys, int P, int *__restrict__ cls_of,
-                                                        int *__restrict__ cand_count) {
+                                                        int *__restrict__ blk_count) {
   __shared__ float sbest[3][64 * VEC];
   __shared__ int sidx[3][64 * VEC];
   const int b = blockIdx.y;
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(256) void nms_decode_filter(const InT *__restrict__
     flag[k] = valid && (a0 + k < A) && (best[k] > conf);
     cnt += flag[k] ? 1 : 0;
   }
-  // wave-level exclusive scan of cnt, one atomic per wave
+  // wave-level exclusive scan of cnt
   int incl = cnt;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -159,11 +166,9 @@ __global__ __launch_bounds__(256) void nms_decode_filter(const InT *__restrict__
     if (lane >= d) incl += t;
   }
   const int total = __shfl(incl, 63);
+  if (lane == 63) blk_count[(size_t)b * gridDim.x + blockIdx.x] = total;
   if (total == 0) return;
-  int base = 0;
-  if (lane == 63) base = atomicAdd(cand_count + b, total);
-  base = __shfl(base, 63);
-  int o = base + incl - cnt;
+  int o = blockIdx.x * (64 * VEC) + incl - cnt;
 #pragma unroll
   for (int k = 0; k < VEC; ++k) {
     if (flag[k]) {
@@ -297,6 +302,71 @@ __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay
   if (!(inter > 0.0f)) return false;  // 0/x and 0/0 never exceed a threshold >= 0
   const float ovr = inter / (aarea + barea - inter);
   return ovr > thr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The candidates of image b, compact: the filter left blk_count[blk] keys at the head of segment blk.  All
+// kSortThreads lanes call this.  Returns n (0: nothing to do) and sets P2 / in_lds; the keys end up in lkeys[0..P2)
+// when they fit the LDS buffer, else in gkeys[0..P2) (through the scratch copy gtmp), padded with zeros.
+// scr: 2 * 256 + 32 ints of LDS.
+constexpr int kGatherChunk = 256;   // segments whose prefix is held in LDS at a time
+
+__device__ int gather_candidates(const int *__restrict__ cnt, int nblk, int seg, int A, int lds_keys, uint64_t *lkeys, uint64_t *gkeys,
+                                 uint64_t *gtmp, int *scr, int &P2, bool &in_lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = kSortThreads / 64;
+  int *wtot = scr, *ccnt = scr + 32, *cpre = scr + 32 + kGatherChunk;
+  int part = 0;
+  for (int i = tid; i < nblk; i += kSortThreads) part += cnt[i];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
+  if (lane == 0) wtot[wave] = part;
+  __syncthreads();
+  int n = 0;
+  for (int w = 0; w < NW; ++w) n += wtot[w];
+  n = min(n, A);
+  __syncthreads();
+  if (n == 0) return 0;
+  P2 = next_pow2(n);
+  in_lds = P2 <= lds_keys;
+  uint64_t *dst = in_lds ? lkeys : gtmp;
+  const int shift = __ffs(seg) - 1;
+  int running = 0;
+  for (int base = 0; base < nblk; base += kGatherChunk) {
+    const int nb = min(kGatherChunk, nblk - base);
+    if (tid < kGatherChunk) {   // waves 0..3: prefix of this chunk's counts
+      const int c = tid < nb ? cnt[base + tid] : 0;
+      int incl = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(incl, d);
+        if (lane >= d) incl += u;
+      }
+      if (lane == 63) wtot[wave] = incl;
+      ccnt[tid] = c;
+      cpre[tid] = incl - c;     // within the wave for now
+    }
+    __syncthreads();
+    int chunk_total = 0;
+    for (int w = 0; w < kGatherChunk / 64; ++w) chunk_total += wtot[w];
+    for (int e = tid; e < (nb << shift); e += kSortThreads) {
+      const int bl = e >> shift, o = e & (seg - 1);
+      if (o < ccnt[bl]) {
+        int pre = running + cpre[bl];
+        for (int w = 0; w < (bl >> 6); ++w) pre += wtot[w];
+        if (pre + o < n) dst[pre + o] = gkeys[((size_t)(base + bl) << shift) + o];
+      }
+    }
+    __syncthreads();
+    running += chunk_total;
+  }
+  if (in_lds) {
+    for (int i = n + tid; i < P2; i += kSortThreads) lkeys[i] = 0ull;
+  } else {
+    for (int i = tid; i < P2; i += kSortThreads) gkeys[i] = i < n ? gtmp[i] : 0ull;
+  }
+  __syncthreads();
+  return n;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -582,7 +652,9 @@ struct SortNmsParams {
   int P;
   const int *cls_of;
   float4 *sbox;
-  const int *cand_count;
+  const int *blk_count;   // [batch][nblk] candidates per filter workgroup
+  int nblk, seg;
+  int scr_off;            // byte offset of the gather's LDS scratch
   float *out_det;
   int *out_count;
   int *out_anchor;
@@ -652,19 +724,15 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
   uint64_t *gkeys = S.keys + (size_t)b * S.P;
   float4 *sbox = S.sbox + (size_t)b * A;
 
-  const int n = min(S.cand_count[b], A);
+  // ---- the image's candidates, compact, into LDS (or the global list when they do not fit) ----------------------
+  int P2 = 0;
+  bool in_lds = true;
+  const int n = gather_candidates(S.blk_count + (size_t)b * S.nblk, S.nblk, S.seg, A, S.lds_keys, lkeys, gkeys,
+                                  reinterpret_cast<uint64_t *>(sbox), reinterpret_cast<int *>(smem + S.scr_off), P2, in_lds);
   if (n == 0) {
     if (tid == 0) S.out_count[b] = 0;
     if (S.fin) finalize_epilogue(S, b, 0, nullptr, nullptr, reinterpret_cast<int *>(smem));
     return;
-  }
-  const int P2 = next_pow2(n);
-  const bool in_lds = P2 <= S.lds_keys;
-
-  // ---- keys into LDS ---------------------------------------------------------------------------------
-  if (in_lds) {
-    for (int i = tid; i < P2; i += kSortThreads) lkeys[i] = (i < n) ? gkeys[i] : 0ull;
-    __syncthreads();
   }
   if (tid < 64) supp[tid] = 0;
   if (tid == 0) *sK = 0;
@@ -691,13 +759,8 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
   // ---- otherwise: sort the whole list, decode the sorted candidates' (class-offset) boxes ----------------------------
   const int n_eff = min(n, S.max_nms);
   if (!done) {
-    if (in_lds) {
-      bitonic_desc_lds(lkeys, P2);
-    } else {
-      for (int i = n + tid; i < P2; i += kSortThreads) gkeys[i] = 0ull;
-      __syncthreads();
-      bitonic_desc(gkeys, P2);
-    }
+    if (in_lds) bitonic_desc_lds(lkeys, P2);
+    else bitonic_desc(gkeys, P2);
     for (int i = tid; i < n_eff; i += kSortThreads) {
       const uint64_t key = in_lds ? lkeys[i] : gkeys[i];
       const uint32_t anchor = ~(uint32_t)key;
@@ -865,22 +928,16 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_rotated(SortNmsParams S
   const InT *pb = reinterpret_cast<const InT *>(S.pred) + (size_t)b * C * A;
   uint64_t *gkeys = S.keys + (size_t)b * S.P;
 
-  const int n = min(S.cand_count[b], A);
+  int P2 = 0;
+  bool in_lds = true;
+  const int n = gather_candidates(S.blk_count + (size_t)b * S.nblk, S.nblk, S.seg, A, S.lds_keys, lkeys, gkeys,
+                                  reinterpret_cast<uint64_t *>(S.sbox + (size_t)b * A), reinterpret_cast<int *>(smem + S.scr_off), P2, in_lds);
   if (n == 0) {
     if (tid == 0) S.out_count[b] = 0;
     return;
   }
-  const int P2 = next_pow2(n);
-  const bool in_lds = P2 <= S.lds_keys;
-  if (in_lds) {
-    for (int i = tid; i < P2; i += kSortThreads) lkeys[i] = (i < n) ? gkeys[i] : 0ull;
-    __syncthreads();
-    bitonic_desc_lds(lkeys, P2);
-  } else {
-    for (int i = n + tid; i < P2; i += kSortThreads) gkeys[i] = 0ull;
-    __syncthreads();
-    bitonic_desc(gkeys, P2);
-  }
+  if (in_lds) bitonic_desc_lds(lkeys, P2);
+  else bitonic_desc(gkeys, P2);
   uint64_t *keys = in_lds ? lkeys : gkeys;
   float4 *box = in_lds ? lbox : S.sbox + (size_t)b * A;
   float2 *cd = in_lds ? lcd : S.scd + (size_t)b * A;
@@ -1143,8 +1200,9 @@ constexpr size_t nms_lds_small(int lds_keys, int max_det) {
   return (size_t)lds_keys * 8 + 4 * 6 * (size_t)((max_det + 1) & ~1) + 64 * 8 + 64 * 4 + 16;
 }
 constexpr size_t nms_lds_rot_head(int lds_keys, int max_det) { return (size_t)lds_keys * 8 + 4 * (size_t)((max_det + 1) & ~1) + 4 * 17 + 16; }
-constexpr size_t kNmsLdsMax = ((nms_lds_small(kSortLdsCap, LMI_MAX_DET_CAP) + 15) & ~(size_t)15) + (size_t)kSortLdsCap * 16;
-constexpr size_t kNmsLdsRotMax = ((nms_lds_rot_head(kSortLdsCap, LMI_MAX_DET_CAP) + 15) & ~(size_t)15) + (size_t)kSortLdsCap * (16 + 8);
+constexpr size_t kGatherLds = sizeof(int) * (2 * kGatherChunk + 32);   // gather_candidates' scratch, behind the box buffer
+constexpr size_t kNmsLdsMax = ((nms_lds_small(kSortLdsCap, LMI_MAX_DET_CAP) + 15) & ~(size_t)15) + (size_t)kSortLdsCap * 16 + kGatherLds;
+constexpr size_t kNmsLdsRotMax = ((nms_lds_rot_head(kSortLdsCap, LMI_MAX_DET_CAP) + 15) & ~(size_t)15) + (size_t)kSortLdsCap * (16 + 8) + kGatherLds;
 static_assert(kNmsLdsMax <= 160 * 1024 && kNmsLdsRotMax <= 160 * 1024, "sort kernels must fit the 160 KiB LDS of a gfx950 CU");
 
 static int nms_device_state(NmsDeviceState **out) {
@@ -1185,7 +1243,7 @@ int64_t lmi_nms_workspace_bytes(int batch, int anchors) {
 struct NmsCall {
   NmsLayout L;
   hipStream_t s;
-  int *cand_count;
+  int *blk_count;
   uint64_t *keys;
   int *cls_of;
   float4 *sbox;
@@ -1207,7 +1265,7 @@ static int nms_check(const void *pred, int pred_dtype, int batch, int nc, int nm
               (long long)workspace_bytes, (long long)C.L.total);
   C.s = reinterpret_cast<hipStream_t>(stream);
   C.ws = reinterpret_cast<unsigned char *>(workspace);
-  C.cand_count = reinterpret_cast<int *>(C.ws + C.L.off_count);
+  C.blk_count = reinterpret_cast<int *>(C.ws + C.L.off_count);
   C.keys = reinterpret_cast<uint64_t *>(C.ws + C.L.off_keys);
   C.cls_of = reinterpret_cast<int *>(C.ws + C.L.off_cls);
   C.sbox = reinterpret_cast<float4 *>(C.ws + C.L.off_sbox);
@@ -1238,18 +1296,16 @@ static int fin_check(const lmi_finalize_args *fin, int batch, int rotated) {
 
 // first half: candidate filter (HBM-bound, reads the head once)
 static int nms_decode(const NmsCall &C, const void *pred, int batch, int nc, int nm, int anchors, float conf_thres) {
-  hipError_t e = hipMemsetAsync(C.cand_count, 0, sizeof(int) * (size_t)batch, C.s);
-  if (e != hipSuccess) { lmi_set_error("lmi_nms_v8: hipMemsetAsync: %s", hipGetErrorString(e)); return LMI_ERR_LAUNCH; }
   const float *pf = reinterpret_cast<const float *>(pred);
   const __half *ph = reinterpret_cast<const __half *>(pred);
-  if ((anchors & 3) == 0) {
-    dim3 grid((anchors / 4 + 63) / 64, batch);
-    if (C.half) hipLaunchKernelGGL((nms_decode_filter<4, __half>), grid, dim3(256), 0, C.s, ph, nc, nm, anchors, conf_thres, C.keys, C.L.P, C.cls_of, C.cand_count);
-    else hipLaunchKernelGGL((nms_decode_filter<4, float>), grid, dim3(256), 0, C.s, pf, nc, nm, anchors, conf_thres, C.keys, C.L.P, C.cls_of, C.cand_count);
+  if (C.L.seg == 256) {
+    dim3 grid(C.L.nblk, batch);
+    if (C.half) hipLaunchKernelGGL((nms_decode_filter<4, __half>), grid, dim3(256), 0, C.s, ph, nc, nm, anchors, conf_thres, C.keys, C.L.P, C.cls_of, C.blk_count);
+    else hipLaunchKernelGGL((nms_decode_filter<4, float>), grid, dim3(256), 0, C.s, pf, nc, nm, anchors, conf_thres, C.keys, C.L.P, C.cls_of, C.blk_count);
   } else {
-    dim3 grid((anchors + 63) / 64, batch);
-    if (C.half) hipLaunchKernelGGL((nms_decode_filter<1, __half>), grid, dim3(256), 0, C.s, ph, nc, nm, anchors, conf_thres, C.keys, C.L.P, C.cls_of, C.cand_count);
-    else hipLaunchKernelGGL((nms_decode_filter<1, float>), grid, dim3(256), 0, C.s, pf, nc, nm, anchors, conf_thres, C.keys, C.L.P, C.cls_of, C.cand_count);
+    dim3 grid(C.L.nblk, batch);
+    if (C.half) hipLaunchKernelGGL((nms_decode_filter<1, __half>), grid, dim3(256), 0, C.s, ph, nc, nm, anchors, conf_thres, C.keys, C.L.P, C.cls_of, C.blk_count);
+    else hipLaunchKernelGGL((nms_decode_filter<1, float>), grid, dim3(256), 0, C.s, pf, nc, nm, anchors, conf_thres, C.keys, C.L.P, C.cls_of, C.blk_count);
   }
   return lmi_check_launch("nms_decode_filter");
 }
@@ -1277,19 +1333,21 @@ static int nms_suppress(const NmsCall &C, const void *pred, int batch, int nc, i
   SortNmsParams S{};
   S.pred = pred; S.nc = nc; S.nm = nm; S.A = anchors; S.iou_thr = thr; S.agnostic = agnostic ? 1 : 0;
   S.max_det = max_det; S.max_nms = max_nms; S.max_wh = max_wh; S.keys = C.keys; S.P = C.L.P; S.cls_of = C.cls_of;
-  S.sbox = C.sbox; S.cand_count = C.cand_count; S.out_det = out_det; S.out_count = out_count; S.out_anchor = out_anchor;
+  S.sbox = C.sbox; S.blk_count = C.blk_count; S.nblk = C.L.nblk; S.seg = C.L.seg; S.out_det = out_det; S.out_count = out_count; S.out_anchor = out_anchor;
   S.lds_keys = C.L.P < kSortLdsCap ? C.L.P : kSortLdsCap;
   S.scd = reinterpret_cast<float2 *>(C.ws + C.L.off_cd);
   if (rotated) {
     LMI_REQUIRE(nm >= 1, LMI_ERR_BAD_ARG, "lmi_nms_v8_rotated: the angle must be the last of nm >= 1 extra channels");
     S.lbox_off = (int)((nms_lds_rot_head(S.lds_keys, max_det) + 15) & ~(size_t)15);
-    const size_t lds_rot = (size_t)S.lbox_off + (size_t)S.lds_keys * (16 + 8);
+    S.scr_off = (int)((size_t)S.lbox_off + (size_t)S.lds_keys * (16 + 8));
+    const size_t lds_rot = (size_t)S.scr_off + kGatherLds;
     if (C.half) hipLaunchKernelGGL(nms_sort_rotated<__half>, dim3(batch), dim3(kSortThreads), lds_rot, C.s, S);
     else hipLaunchKernelGGL(nms_sort_rotated<float>, dim3(batch), dim3(kSortThreads), lds_rot, C.s, S);
     return lmi_check_launch("nms_sort_rotated");
   }
   S.lbox_off = (int)((nms_lds_small(S.lds_keys, max_det) + 15) & ~(size_t)15);
-  size_t lds = (size_t)S.lbox_off + (size_t)S.lds_keys * 16;
+  S.scr_off = (int)((size_t)S.lbox_off + (size_t)S.lds_keys * 16);
+  size_t lds = (size_t)S.scr_off + kGatherLds;
   if (fin) {
     S.fin = 1;
     fin_params(fin, out_det, out_count, batch, max_det, 6 + nm, nc, S.F);
