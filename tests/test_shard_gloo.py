@@ -48,6 +48,9 @@ def _rank_main(rank, world, port, q):
     lo, hi = shard.shard_bounds(head.shape[0], world, rank)
     kept, chk = _work(head, lo, hi)
     rep = shard.gather_report({"images": hi - lo, "kept": kept, "chk_hi": chk >> 31, "chk_lo": chk & (2**31 - 1), "t": 0.1 * (rank + 1)})
+    # per-block timings as bench.py gathers them: the slowest rank per block, then the median block
+    blocks = shard.gather_vector(torch.tensor([1.0, 3.0, 2.0]) * (rank + 1))
+    rep[0]["median_of_max"] = float(torch.stack(blocks).max(dim=0).values.median())
     dist.barrier()
     if rank == 0:
         q.put(rep)
@@ -68,6 +71,7 @@ def test_two_rank_gloo_matches_single_process():
     head = synth.head(np.random.default_rng(4), 6, 8, 0, 160, objects=6)
     kept, chk = _work(head, 0, 6)
     assert len(rep) == 2 and sum(r["images"] for r in rep) == 6
+    assert rep[0].pop("median_of_max") == 4.0      # max over ranks = [2, 6, 4] -> median 4
     assert sum(r["kept"] for r in rep) == kept and kept > 0
     total = sum((int(r["chk_hi"]) << 31) | int(r["chk_lo"]) for r in rep) % (2**61 - 1)
     assert total == chk
@@ -76,3 +80,22 @@ def test_two_rank_gloo_matches_single_process():
 
 def test_gather_report_without_group():
     assert shard.gather_report({"a": 1.0}) == [{"a": 1.0}]
+
+
+def test_gather_vector_without_a_process_group():
+    out = shard.gather_vector(torch.tensor([0.5, 0.25]))
+    assert len(out) == 1 and out[0].dtype == torch.float64 and out[0].tolist() == [0.5, 0.25]
+
+
+def test_roofline_byte_counts():
+    from object_detectors_amd import roofline as R
+    assert R.letterbox_bytes(1080, 1920, 640, 640) == 7_680_000 == R.letterbox_bytes(2160, 3840, 640, 640)
+    assert R.letterbox_row_granular_bytes(2160, 3840, 640, 640) == 720 * 11520 + 4_915_200
+    # exact upsample bytes: the whole mask once + only the logits rows x columns under the box
+    whole = R.mask_upsample_bytes(1, 1080, 1920, 160, 160)
+    assert whole == 1080 * 1920 + 90 * 160 * 4
+    full = R.mask_upsample_bytes_exact(np.array([[0.0, 0.0, 1920.0, 1080.0]]), 1080, 1920, 160, 160)
+    assert full == whole
+    small = R.mask_upsample_bytes_exact(np.array([[100.0, 100.0, 400.0, 300.0]]), 1080, 1920, 160, 160)
+    assert 1080 * 1920 < small < 1080 * 1920 + 30 * 30 * 4
+    assert R.mask_upsample_bytes_exact(np.array([[5.0, 5.0, 5.0, 9.0]]), 1080, 1920, 160, 160) == 1080 * 1920   # empty box: zeros only
