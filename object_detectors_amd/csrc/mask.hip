@@ -448,11 +448,11 @@ __global__ __launch_bounds__(256) void mask_zero_fill_kernel(const int *__restri
 }
 
 // Second pass of the split path: the chunks that meet a slot's box, and nothing else.  grid: x = row strips, y = slot.
-// Every lane owns one 16-byte chunk column of the box and walks down the strip's box rows, so the horizontal taps and
+// Every lane owns one 16-byte chunk column of the box and walks down the strip's box rows, so the horizontal
 // weights of its pixels are computed once and all lanes of a wave have work (a lane-per-chunk sweep over whole rows
 // leaves ~3/4 of the lanes idle on boxes ~1/7 of the frame wide).  Same arithmetic as mask_upsample_kernel.
 template <typename OutT>
-__global__ __launch_bounds__(256) void mask_box_kernel(UpParams U) {
+__global__ __launch_bounds__(256, 4) void mask_box_kernel(UpParams U) {   // 4 waves per SIMD: at most 128 VGPRs
   using MO = MaskOut<OutT>;
   constexpr int PX = MO::PX;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -473,7 +473,17 @@ __global__ __launch_bounds__(256) void mask_box_kernel(UpParams U) {
   if (U.M.images && off + (long long)H0 * W0 > U.out_elems) return;
   OutT *out = reinterpret_cast<OutT *>(U.out) + off;
 
-  const int ca = t.x / PX, cb = (t.y + PX - 1) / PX;   // chunk columns that meet the box (rows are whole chunks)
+  int ca = t.x / PX, cb = (t.y + PX - 1) / PX;   // chunk columns that meet the box (rows are whole chunks)
+  // ... widened to whole 64-byte blocks where the rows allow it: a store that covers part of a block costs more than
+  // the bytes it saves (this pass's stores alone, no arithmetic: 71 us as the boxes fall, 50 us on whole 128-byte
+  // lines although those are ~40 % more bytes).  The added chunks lie outside the box and come out as zeros through
+  // the same arithmetic (a branch for them serialises against the other lanes' work: slower); 64 bytes is where
+  // the cheaper stores and the extra arithmetic balance (84 us unaligned, 78 / 72 / 85 us at 32 / 64 / 128 bytes).
+  constexpr int kBlock = 64 / 16;
+  if (((size_t)W0 * sizeof(OutT)) % 64 == 0 && ((size_t)off * sizeof(OutT)) % 64 == 0) {
+    ca = ca / kBlock * kBlock;
+    cb = (cb + kBlock - 1) / kBlock * kBlock;
+  }
   // Staged: the logits rows this strip's box rows read, and of those only the columns its chunk columns read, plus
   // one more column (the last logits column repeated past the right border): the right-hand tap of a pixel is then
   // always the next float -- ix1 == ix0 only at the right border, where both taps read the last column -- and one
@@ -496,12 +506,18 @@ __global__ __launch_bounds__(256) void mask_box_kernel(UpParams U) {
     __syncthreads();
   }
 
-  const int lpr = min(cb - ca, 256);                   // lanes per row
-  const int groups = 256 / lpr;                        // row groups: each takes consecutive rows of the strip
-  const int lr = threadIdx.x / lpr, lc = threadIdx.x - lr * lpr;
-  if (lr >= groups) return;
-  const int rows_per_group = (rb - ra + groups - 1) / groups;
-  const int y_first = ra + lr * rows_per_group, y_last = min(y_first + rows_per_group, rb);
+  // Each wave takes a quarter of the strip's box rows and sweeps it in address order, R adjacent rows per store
+  // instruction (a box ~300 bytes wide: 3 rows).  The pass is bound by its stores (no stores: 53 us, stores alone:
+  // 88 us of 91 on seg640), and lanes that each walk their own run of rows -- more reuse of the horizontal taps --
+  // scatter one instruction's stores over rows far apart: 91 us against 84 us this way.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lpr = min(cb - ca, 64);                    // lanes per row
+  const int R = 64 / lpr, rsub = lane / lpr;
+  const int lc = lane - rsub * lpr;
+  if (rsub >= R) return;
+  const int q = (rb - ra + 3) >> 2;
+  const int y0w = ra + wave * q;
+  const int y_first = y0w + rsub, y_last = min(y0w + q, rb), ystep = R;
   for (int chunk = ca + lc; chunk < cb; chunk += lpr) {
     const int x0 = chunk * PX;
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -528,7 +544,7 @@ __global__ __launch_bounds__(256) void mask_box_kernel(UpParams U) {
     };
     f2 tu[PX / 2], tl[PX / 2];   // upper / lower source row, interpolated horizontally; adjacent pixels paired for packed math
     int cur0 = -1, cur1 = -1;
-    for (int y = y_first; y < y_last; ++y) {
+    for (int y = y_first; y < y_last; y += ystep) {
       int iy0, iy1; float ly0, ly1;
       bilinear_src(scale_h, y, wh, iy0, iy1, ly0, ly1);
       if (iy0 != cur0 || iy1 != cur1) {
