@@ -1,7 +1,7 @@
 """Print one step's kernel timeline (start offset, duration, gap to the previous end) from a rocprofv3 kernel trace.
 usage: python scratch/timeline.py gpurun_out/trace_TAG [step-index-from-end]"""
 import csv, glob, sys
-f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
+f = max(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True), key=__import__("os").path.getmtime)
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", "")) for r in csv.DictReader(open(f))]
 rows.sort()
 # a step starts at each nms_decode_filter
