@@ -156,7 +156,9 @@ struct OutTraits<__half> {
 
 // Workgroup = (TW/4) x TH lanes; lane (g, r) produces output pixels x = tile_x0 + 4g .. +3 of
 // row tile_y0 + r.  LDS holds only the staged source rows.
-template <typename OutT, int TW, int TH>
+// KF = 16-byte staging loads a lane keeps in flight: as many as a staged row has chunks per lane (4K -> 640: 10), no
+// more -- a load past the row's span is dropped by the range check but still costs its issue slot.
+template <typename OutT, int TW, int TH, int KF>
 __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
   constexpr int NT = (TW / 4) * TH;
   extern __shared__ __attribute__((aligned(16))) unsigned char rows[];
@@ -245,20 +247,20 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
     if (row >= 0) {
       const uint32_t goff = (uint32_t)((long long)row * stride + span_b0);
       const uint32_t aligned = goff & ~15u;
-      // four loads in flight per lane before the first LDS write: the loop is latency-bound otherwise (4K frames
-      // need 9 chunks per lane).  Loads past the row's span get an out-of-range offset (dropped by the range check, no
-      // traffic) and their LDS writes are skipped.
-      for (int ch = tid % LPS; ch < nchunk; ch += 4 * LPS) {
-        auto v0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, aligned + 16u * ch, 0, 0);
-        constexpr uint32_t kOut = 0xfffffff0u;  // beyond num_records: the load is dropped without touching memory
-        auto v1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ch + LPS < nchunk ? aligned + 16u * (ch + LPS) : kOut, 0, 0);
-        auto v2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ch + 2 * LPS < nchunk ? aligned + 16u * (ch + 2 * LPS) : kOut, 0, 0);
-        auto v3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ch + 3 * LPS < nchunk ? aligned + 16u * (ch + 3 * LPS) : kOut, 0, 0);
+      // KF loads in flight per lane before the first LDS write: the loop is latency-bound otherwise (4K frames need 10
+      // chunks per lane: 169.5 us with 4 in flight, 159.3 us with 12).  Loads past the row's span get an out-of-range
+      // offset (dropped by the range check, no traffic) and their LDS writes are skipped.
+      constexpr uint32_t kOut = 0xfffffff0u;  // beyond num_records: the load is dropped without touching memory
+      for (int ch = tid % LPS; ch < nchunk; ch += KF * LPS) {
+        using chunk_t = decltype(__builtin_amdgcn_raw_buffer_load_b128(rsrc, 0, 0, 0));
+        chunk_t v[KF];
+#pragma unroll
+        for (int j = 0; j < KF; ++j)
+          v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ch + j * LPS < nchunk ? aligned + 16u * (ch + j * LPS) : kOut, 0, 0);
         unsigned char *q = rows + slot * P.pitch + 16 * ch;
-        *reinterpret_cast<decltype(v0) *>(q) = v0;
-        if (ch + LPS < nchunk) *reinterpret_cast<decltype(v0) *>(q + 16 * LPS) = v1;
-        if (ch + 2 * LPS < nchunk) *reinterpret_cast<decltype(v0) *>(q + 32 * LPS) = v2;
-        if (ch + 3 * LPS < nchunk) *reinterpret_cast<decltype(v0) *>(q + 48 * LPS) = v3;
+#pragma unroll
+        for (int j = 0; j < KF; ++j)
+          if (ch + j * LPS < nchunk) *reinterpret_cast<chunk_t *>(q + 16 * j * LPS) = v[j];
       }
     }
   }
@@ -294,6 +296,17 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
       }
       const uint32_t aw = (uint32_t)xa_[k];
       const int a0 = (int)(aw & 0xffffu), a1 = (int)(aw >> 16);
+      if ((a1 | b1) == 0) {
+        // Both second weights are 0 (a0 = b0 = 2048): the fixed-point sum is the left upper tap itself,
+        // ((2048 * ((s * 2048) >> 4)) >> 16 + 2) >> 2 = s.  Every pixel of an exact odd reduction (1080p -> 640x360:
+        // fx = 3 dx + 1) or of a frame already at model size takes this branch: one tap, no arithmetic.
+        const int p = base0 + s * 3;
+        const int wi = p >> 2;
+        const uint32_t t = __builtin_amdgcn_alignbyte(rw[wi + 1], rw[wi], (uint32_t)(p & 3));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[c][k] = TR::make((int)((t >> (8 * c)) & 0xffu));
+        continue;
+      }
       uint32_t px[2][2];  // [row][0: bytes p..p+3, 1: bytes p+4..p+7]
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr) {
@@ -511,14 +524,17 @@ int launch_letterbox(const LbParams &P0, int batch, int sets, int max_pitch128, 
     P.tiles_x = (P.dst_w + 127) / 128;
     P.tiles_y = (P.dst_h + kTH - 1) / kTH;
     dim3 grid(P.tiles_x * P.tiles_y, batch);
-    hipLaunchKernelGGL((letterbox_kernel<OutT, 128, kTH>), grid, dim3(32 * kTH), lds_bytes_for(P.pitch), stream, P);
+    // chunks per lane of a staged row: pitch / 16 bytes over the 16 lanes that share the row
+    if (P.pitch > 8 * 256) hipLaunchKernelGGL((letterbox_kernel<OutT, 128, kTH, 12>), grid, dim3(32 * kTH), lds_bytes_for(P.pitch), stream, P);
+    else if (P.pitch > 4 * 256) hipLaunchKernelGGL((letterbox_kernel<OutT, 128, kTH, 8>), grid, dim3(32 * kTH), lds_bytes_for(P.pitch), stream, P);
+    else hipLaunchKernelGGL((letterbox_kernel<OutT, 128, kTH, 4>), grid, dim3(32 * kTH), lds_bytes_for(P.pitch), stream, P);
   } else if (lds_bytes_for(max_pitch32) <= 2 * kMaxLds) {
     P.pitch = max_pitch32;
     P.tiles_x = (P.dst_w + 31) / 32;
     P.tiles_y = (P.dst_h + kTH - 1) / kTH;
     dim3 grid(P.tiles_x * P.tiles_y, batch);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(letterbox_kernel<OutT, 32, kTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)kMaxLds);
-    hipLaunchKernelGGL((letterbox_kernel<OutT, 32, kTH>), grid, dim3(8 * kTH), lds_bytes_for(P.pitch), stream, P);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(letterbox_kernel<OutT, 32, kTH, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)kMaxLds);
+    hipLaunchKernelGGL((letterbox_kernel<OutT, 32, kTH, 4>), grid, dim3(8 * kTH), lds_bytes_for(P.pitch), stream, P);
   } else {
     lmi_set_error("lmi_letterbox_u8: down-scale factor too large for the LDS row tiles");
     return LMI_ERR_LIMIT;
