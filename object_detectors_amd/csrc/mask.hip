@@ -262,11 +262,23 @@ __global__ __launch_bounds__(256) void mask_logits_rows_kernel(GemmParams G) {
 
   // Issued before anything depends on the survivor list, so the loads overlap the staging below.  Rows nobody
   // reads are loaded too: with ~47 boxes per image nearly every window row is under some box.
+  // Buffer loads: one VGPR offset for the lane's pixel pair, the channel's plane as the scalar offset -- 32 separate
+  // 64-bit addresses would cost 64 VGPRs at the point where all loads are in flight.  A lane beyond the window gets an
+  // offset past num_records: its loads are dropped and return 0.
   float2v bf[32];
+  {
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(reinterpret_cast<uintptr_t>(pb) & 0xffffffffu));
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(reinterpret_cast<uintptr_t>(pb) >> 32));
+    const void *ubase = reinterpret_cast<const void *>(((uintptr_t)hi << 32) | lo);
+    const uint32_t bytes = (uint32_t)((31u * (uint32_t)plane + (uint32_t)npx) * 4u);   // this image's window, channel 0 .. 31
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ubase), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+    const uint32_t voff = pv ? (uint32_t)p * 4u : 0xfffffff0u;
 #pragma unroll
-  for (int k = 0; k < 32; ++k) {
-    const float2v z = {0.0f, 0.0f};
-    bf[k] = pv ? *reinterpret_cast<const float2v *>(pb + (size_t)k * plane + p) : z;
+    for (int k = 0; k < 32; ++k) {
+      auto t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, (uint32_t)k * (uint32_t)plane * 4u, 0);
+      const uint32_t t0 = t[0], t1 = t[1];   // (a bit_cast applied to a vector element reads element 0 both times)
+      bf[k] = float2v{__uint_as_float(t0), __uint_as_float(t1)};
+    }
   }
 
   for (int s0 = 0; s0 < m_b; s0 += kSurvBatch) {
