@@ -213,55 +213,55 @@ __global__ __launch_bounds__(256) void mask_gemm_kernel(GemmParams G) {
   }
 }
 
-// Row-sparse variant of the GEMM on the vector ALU, used when prototype rows are whole 8-byte pairs.
-// A survivor's upsample reads only the logits rows under its box, typically a tenth of the window, so the dense
-// 32-survivor MFMA tile above spends most of its issue slots on rows nobody reads (measured 82 us per seg640
-// launch, MFMA-issue bound).  Here a wave keeps 128 consecutive window pixels x 32 channels in registers (2 px per
-// lane) and walks the image's survivors, doing the k-ordered fmaf chain only for those whose row range meets the
-// wave's pixels; coefficients and row ranges sit in LDS and are read as broadcasts.
-// grid: x = groups of 4 pixel tiles (one per wave), y = image
-constexpr int kSurvBatch = 128;  // survivors staged per pass: 128 * (32 coef + 2 range) * 4 B = 17 KiB of LDS
+// Box-sparse variant of the GEMM on the vector ALU, used when prototype rows are whole 8-byte pairs.
+// A survivor's upsample reads only the logits under its box -- typically a tenth of the window's rows and a sixth of
+// its columns -- so the dense 32-survivor MFMA tile above spends most of its issue slots on values nobody reads
+// (measured 82 us per seg640 launch, MFMA-issue bound).  Here a wave keeps a tile of 32 columns x 4 rows of the window
+// x 32 channels in registers (2 adjacent px per lane; every row segment of a load is one 128-byte line) and walks the
+// image's survivors, doing the k-ordered fmaf chain only for those whose logits rows AND columns meet the tile;
+// coefficients and ranges sit in LDS and are read as broadcasts.  The column range is the one mask_box_kernel and
+// mask_upsample_kernel can read at most: the box's pixel columns widened to 64-pixel blocks, through the same
+// source-index arithmetic, plus the right-hand tap.
+// grid: x = groups of 4 tiles (one per wave), y = image
+constexpr int kSurvBatch = 128;  // survivors staged per pass: 128 * (32 coef + 4 range) * 4 B = 18 KiB of LDS
+constexpr int kLogitTileW = 32, kLogitTileH = 4;
 
-__global__ __launch_bounds__(256) void mask_logits_rows_kernel(GemmParams G) {
+__global__ __launch_bounds__(256, 4) void mask_logits_rows_kernel(GemmParams G) {
   typedef float float2v __attribute__((ext_vector_type(2)));
   __shared__ __attribute__((aligned(16))) float coef[kSurvBatch][32];
-  __shared__ int rlo[kSurvBatch], rhi[kSurvBatch];
+  __shared__ int4 rng[kSurvBatch];   // logits rows {lo, hi} and prototype columns {lo, hi} a survivor's upsample reads
+  __shared__ int emap[kSurvBatch];   // det row of each staged survivor
 
   const int b = blockIdx.y;
   const int base = G.slot_base[b];
   const int m_b = G.slot_base[b + 1] - base;
   if (m_b <= 0) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const MaskGeom g = image_geom(G.M, b);
-  const int wh = g.bottom - g.top, mw = g.mw;
-  const int npx = wh * mw;
+  const int wh = g.bottom - g.top, ww = g.right - g.left, mw = g.mw;
   const int plane = g.mh * mw;
   const float *pb = G.proto + (size_t)b * 32 * plane + (size_t)g.top * mw;
-  const float scale_h = (float)wh / (float)g.h0;
-  if (blockIdx.x > 0 && (int)blockIdx.x * 512 >= npx) return;   // ragged batch: the grid spans the largest window
+  const float scale_h = (float)wh / (float)g.h0, scale_w = (float)ww / (float)g.w0;
+  const int tiles_x = (mw + kLogitTileW - 1) / kLogitTileW;
+  // ragged batch: the grid spans the largest window
+  if (blockIdx.x > 0 && ((int)blockIdx.x * 4 / tiles_x) * kLogitTileH >= wh) return;
 
-  const int p0 = (blockIdx.x * 4 + wave) * 128;
-  const int p = p0 + 2 * lane;
-  const bool pv = p < npx;                 // mw even: a lane's two pixels are valid together and share a row
-  const int prow = pv ? p / mw : -1;
-  const int ra = p0 < npx ? p0 / mw : 0x7fffffff;   // rows this wave touches
-  const int rb = p0 < npx ? min(p0 + 127, npx - 1) / mw : -1;
+  const int tile = blockIdx.x * 4 + wave;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int ra = ty * kLogitTileH, rb = ra + kLogitTileH - 1;      // rows and columns of this wave's tile
+  const int ca = tx * kLogitTileW, cb = ca + kLogitTileW - 1;
+  const int prow = ra + (lane >> 4), pcol = ca + 2 * (lane & 15);
+  const bool pv = prow < wh && pcol < mw;      // mw even: a lane's two pixels are valid together
+  const int p = prow * mw + pcol;
 
-  auto row_range = [&](const float *d, int &lo, int &hi) {
-    const float bx1 = d[0], by1 = d[1], bx2 = d[2], by2 = d[3];
-    lo = 1; hi = 0;
-    const int ya = max(0, (int)ceilf(by1)), yb = min(g.h0, (int)ceilf(by2));
-    if (ya < yb && bx1 < bx2) {  // same arithmetic as mask_upsample_kernel
-      int i0, i1; float l0, l1;
-      bilinear_src(scale_h, ya, wh, i0, i1, l0, l1);
-      lo = i0;
-      bilinear_src(scale_h, yb - 1, wh, i0, i1, l0, l1);
-      hi = i1;
-    }
-  };
+  // The staging below is a chain of dependent loads (slot_base -> slot_map -> det row).  Loads return in order, so a
+  // slot_map load issued after the 32 prototype loads would only be seen once all of those have landed, and the det
+  // rows one more round trip later: the first batch's slot_map entries are requested BEFORE the prototype loads.
+  int e_first = 0;
+  if ((int)threadIdx.x < min(kSurvBatch, m_b)) e_first = G.slot_map[base + threadIdx.x];
 
-  // Issued before anything depends on the survivor list, so the loads overlap the staging below.  Rows nobody
-  // reads are loaded too: with ~47 boxes per image nearly every window row is under some box.
+  // Issued before anything depends on the survivor list, so the loads overlap the staging below.  Tiles nobody
+  // reads are loaded too: with ~47 boxes per image nearly every tile is under some box.
   // Buffer loads: one VGPR offset for the lane's pixel pair, the channel's plane as the scalar offset -- 32 separate
   // 64-bit addresses would cost 64 VGPRs at the point where all loads are in flight.  A lane beyond the window gets an
   // offset past num_records: its loads are dropped and return 0.
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void mask_logits_rows_kernel(GemmParams G) {
     uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(reinterpret_cast<uintptr_t>(pb) & 0xffffffffu));
     uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(reinterpret_cast<uintptr_t>(pb) >> 32));
     const void *ubase = reinterpret_cast<const void *>(((uintptr_t)hi << 32) | lo);
-    const uint32_t bytes = (uint32_t)((31u * (uint32_t)plane + (uint32_t)npx) * 4u);   // this image's window, channel 0 .. 31
+    const uint32_t bytes = (uint32_t)((31u * (uint32_t)plane + (uint32_t)(wh * mw)) * 4u);   // this image's window, channel 0 .. 31
     auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ubase), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
     const uint32_t voff = pv ? (uint32_t)p * 4u : 0xfffffff0u;
 #pragma unroll
@@ -284,30 +284,46 @@ __global__ __launch_bounds__(256) void mask_logits_rows_kernel(GemmParams G) {
   for (int s0 = 0; s0 < m_b; s0 += kSurvBatch) {
     const int ns = min(kSurvBatch, m_b - s0);
     __syncthreads();  // the previous batch's readers are done
-    // stage coefficients (one 128-byte row per survivor) and row ranges
+    if ((int)threadIdx.x < ns) emap[threadIdx.x] = s0 == 0 ? e_first : G.slot_map[base + s0 + threadIdx.x];
+    __syncthreads();
+    // stage coefficients (one 128-byte row per survivor) and ranges
     for (int idx = threadIdx.x; idx < ns * 32; idx += 256) {
       const int i = idx >> 5, k = idx & 31;
-      coef[i][k] = G.det[(size_t)G.slot_map[base + s0 + i] * G.det_stride + 6 + k];
+      coef[i][k] = G.det[(size_t)emap[i] * G.det_stride + 6 + k];
     }
     if (threadIdx.x < ns) {
-      int lo, hi;
-      const float *d = G.det + (size_t)G.slot_map[base + s0 + threadIdx.x] * G.det_stride;
-      row_range(d, lo, hi);
-      rlo[threadIdx.x] = lo;
-      rhi[threadIdx.x] = hi;
+      const float *d = G.det + (size_t)emap[threadIdx.x] * G.det_stride;
+      const int4 t = box_ranges(d[0], d[1], d[2], d[3], g.h0, g.w0);   // {xa, xb, ya, yb}, all zero for an empty box
+      int4 r = make_int4(1, 0, 1, 0);
+      if (t.y > t.x) {  // same arithmetic as the upsample kernels
+        int i0, i1; float l0, l1;
+        bilinear_src(scale_h, t.z, wh, i0, i1, l0, l1);
+        r.x = i0;
+        bilinear_src(scale_h, t.w - 1, wh, i0, i1, l0, l1);
+        r.y = i1;
+        bilinear_src(scale_w, t.x & ~63, ww, i0, i1, l0, l1);
+        r.z = g.left + i0;
+        bilinear_src(scale_w, min((t.y + 63) & ~63, g.w0) - 1, ww, i0, i1, l0, l1);
+        r.w = g.left + min(i0 + 1, ww - 1);
+      }
+      rng[threadIdx.x] = r;
       const long long slot = (long long)base + s0 + threadIdx.x;   // the upsample's box pass reads this record
-      if (blockIdx.x == 0 && slot < G.capacity) G.table[slot] = box_ranges(d[0], d[1], d[2], d[3], g.h0, g.w0);
+      if (blockIdx.x == 0 && slot < G.capacity) G.table[slot] = t;
     }
     __syncthreads();
 
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)   // interleaved two-fold the loop holds two survivors' coefficients: +32 VGPRs
     for (int i = 0; i < ns; ++i) {
-      const int lo = rlo[i], hi = rhi[i];
-      if (hi < ra || lo > rb) continue;  // wave-uniform
+      const int4 r = rng[i];
+      if (r.y < ra || r.x > rb || r.w < ca || r.z > cb) continue;  // wave-uniform
       const long long slot = (long long)base + s0 + i;
       if (slot >= G.capacity) continue;
       float2v acc = {0.0f, 0.0f};
 #pragma unroll
       for (int k4 = 0; k4 < 8; ++k4) {
+        // the second half's coefficients are not read before the first half is used up: 16 fewer live VGPRs, which is
+        // what brings the kernel to 128 (4 waves per SIMD) without spills
+        if (k4 == 4) __builtin_amdgcn_sched_barrier(0);
         const float4 c = *reinterpret_cast<const float4 *>(&coef[i][4 * k4]);
         const float cc[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
@@ -316,7 +332,8 @@ __global__ __launch_bounds__(256) void mask_logits_rows_kernel(GemmParams G) {
           acc = __builtin_elementwise_fma(cv, bf[4 * k4 + j], acc);
         }
       }
-      if (prow >= lo && prow <= hi) *reinterpret_cast<float2v *>(G.logits + (size_t)slot * G.lstride + p) = acc;
+      if (pv && prow >= r.x && prow <= r.y && pcol + 1 >= r.z && pcol <= r.w)
+        *reinterpret_cast<float2v *>(G.logits + (size_t)slot * G.lstride + p) = acc;
     }
   }
 }
@@ -772,7 +789,7 @@ int lmi_mask_logits_ex(const float *proto, int batch, int nm, int mh, int mw, co
   const int npx = C.max_wh * mw;   // the largest window of the batch; tiles beyond an image's own window leave at once
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (!(flags & LMI_MASK_LOGITS_MFMA) && (mw % 2) == 0 && lmi_is_aligned(proto, 8)) {
-    const int tiles = (npx + 127) / 128;
+    const int tiles = ((mw + kLogitTileW - 1) / kLogitTileW) * ((C.max_wh + kLogitTileH - 1) / kLogitTileH);
     hipLaunchKernelGGL(mask_logits_rows_kernel, dim3((tiles + 3) / 4, batch), dim3(256), 0, s, G);
     return lmi_check_launch("mask_logits_rows_kernel");
   }
