@@ -108,7 +108,7 @@ class Pipeline:
         self.nms_out, self.fin_out = r[:3], r[3]
         return r
 
-    def step(self, i=0, time_upsample=None, time_letterbox=None, fork=True):
+    def step(self, i=0, time_upsample=None, time_letterbox=None, fork=True, join=True):
         """One pass of the hot path over batch i of the pool.  The letterbox and the NMS chain do not depend on each
         other.  Side by side from the start they gain nothing (both the letterbox and the NMS candidate filter are
         HBM-bound, and the sort + suppression workgroups that follow starve behind the letterbox's), so the
@@ -124,7 +124,20 @@ class Pipeline:
             self.side.wait_event(self.decode_done)
             with torch.cuda.stream(self.side):
                 self._letterbox(i, time_letterbox)
-        return self._post(i, time_upsample, join=(lambda: main.wait_stream(self.side)) if fork else None)
+        # join=False (detection workloads inside a block graph): the next step's candidate filter need not wait for this
+        # step's letterbox -- the letterboxes stay ordered on the side stream, the block's last step joins
+        do_join = fork and (join or self.cfg["nm"])
+        return self._post(i, time_upsample, join=(lambda: main.wait_stream(self.side)) if do_join else None)
+
+    def run_block(self, steps):
+        """`steps` consecutive steps (batch k % pool of step k), every one with its own fork; detection workloads join
+        the letterbox stream once, at the end of the block -- the next step's candidate filter need not wait for this
+        step's letterbox (the letterboxes stay ordered on their own stream).  Segmentation steps join before their zero
+        fill as always: nothing runs beside it.  (Tried for them and dropped: the next step's NMS chain on a third
+        stream beside this step's box pass, outputs double-buffered -- the box pass shares the chip with nothing:
+        seg640 1.244 against 1.247 ms/step, seg1280 1.062 against 1.060.)"""
+        for k in range(steps):
+            self.step(k % len(self.pool), join=(k == steps - 1))
 
     def _letterbox(self, i, time_letterbox):
         if time_letterbox is not None:
@@ -197,6 +210,10 @@ def main():
                     "one captured HIP graph per step (the default; the per-kernel roofline timing then comes from an eager, "
                     "event-timed pass right after the timed region)")
     ap.add_argument("--graph", action="store_true", help=argparse.SUPPRESS)   # the default since r01; kept for old command lines
+    ap.add_argument("--no-pipeline-steps", dest="pipeline_steps", action="store_false",
+                    help="inside a block graph, join the letterbox stream at the end of every step instead of only at the block's end")
+    ap.add_argument("--no-block-graph", dest="block_graph", action="store_false",
+                    help="replay one HIP graph per step instead of one graph per timed block of --steps steps")
     ap.add_argument("--no-fork", action="store_true", help="run the letterbox and the NMS chain on one stream (measurement)")
     ap.add_argument("--mask-logits", default="rows", choices=["rows", "mfma"],
                     help="coefficient x prototype product: row-sparse vector-ALU kernel (default) or dense fp32 MFMA tiles "
@@ -244,8 +261,11 @@ def main():
 
     for k in range(max(args.warmup, 1)):
         out = pipe.step(k % len(pool), fork=fork)
+    if fork and args.pipeline_steps and args.block_graph and not args.eager:
+        pipe.run_block(2 * len(pool))   # eager once: every stream's workspace exists before the capture
     barrier()
     graphs = None
+    block_graph = None
     if not args.eager:
         try:   # one step = one HIP graph per pool entry (both streams of the fork are captured through the event dependencies)
             graphs = []
@@ -257,9 +277,23 @@ def main():
                 g.replay()
                 graphs.append(g)
             barrier()
+            if args.block_graph and steps <= 512:
+                # the whole timed block as ONE graph (the steps still rotate through the pool, every step with its own
+                # fork and join): between two graph launches the GPU idles ~15 us, 10 % of a detection step
+                bg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(bg, capture_error_mode="thread_local"):
+                    if args.pipeline_steps and fork:
+                        pipe.run_block(steps)
+                    else:
+                        for k in range(steps):
+                            out = pipe.step(k % len(pool), fork=fork)
+                bg.replay()
+                block_graph = bg
+                barrier()
         except Exception as e:   # noqa: BLE001 -- a capture problem must not cost the measurement
             log(f"[bench r{rank}] HIP graph capture failed ({type(e).__name__}: {e}); eager launches instead")
             graphs = None
+            block_graph = None
             torch.cuda.synchronize()
             out = pipe.step(0, fork=fork)
             barrier()
@@ -269,11 +303,13 @@ def main():
     for _ in range(max(args.blocks, 1)):
         barrier()
         t0 = time.perf_counter()
-        for k in range(steps):
+        for k in range(steps if block_graph is None else 0):
             if graphs is not None:
                 graphs[k % len(pool)].replay()
             else:
                 out = pipe.step(k % len(pool), fork=fork)
+        if block_graph is not None:
+            block_graph.replay()
         barrier()
         block_s.append(time.perf_counter() - t0)
     # max over ranks per block, then the median block
@@ -375,8 +411,10 @@ def main():
                        "input_pool": f"{len(pool)} distinct device-resident batches, rotated every step",
                        "total_images": args.images if args.images > 0 else None,
                        "per_rank": [{"images": int(r["images"]), "survivors": int(r["survivors"]), "kept_checksum": (int(r["chk_hi"]) << 31) | int(r["chk_lo"])} for r in reports],
-                       "mask_dtype": "uint8", "forward": "excluded", "launch": "hip graph replay" if graphs is not None else "eager",
+                       "mask_dtype": "uint8", "forward": "excluded", "launch": ("one hip graph per block of %d steps" % steps) if block_graph is not None else "one hip graph replay per step" if graphs is not None else "eager",
                        "streams": "letterbox forked beside NMS sort+suppress+finalize" if fork else "one", "mask_logits": args.mask_logits,
+                       "step_overlap": ("letterbox stream joined once per block: step k+1's candidate filter may run beside step k's letterbox"
+                                        if (block_graph is not None and args.pipeline_steps and fork and not cfg["nm"]) else "none: every step joins its streams"),
                        "sharding": f"{world} x independent batches, no collective on the hot path"},
             "roofline": roof, "cpu_baseline": cpu,
         }

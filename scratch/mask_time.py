@@ -25,6 +25,6 @@ st = torch.cuda.current_stream().cuda_stream
 args = (B, nm, 160, 160, det.data_ptr(), 300, 38, fin["slot_map"].data_ptr(), fin["slot_base"].data_ptr(), h0, w0, None, None)
 logits = lambda: _lib.check(L.lmi_mask_logits_ex(proto.data_ptr(), *args, total, ws.data_ptr(), ws.numel(), 0, st))
 ovf = torch.zeros(1, dtype=torch.int32, device="cuda")
-up = lambda: _lib.check(L.lmi_mask_upsample_ex(ws.data_ptr(), *args, out.data_ptr(), 2, total, 0, ovf.data_ptr(), 0, st))
+up = lambda: _lib.check(L.lmi_mask_upsample_ex(ws.data_ptr(), *args, out.data_ptr(), 2, total, 0, ovf.data_ptr(), int(os.environ.get("LMI_FLAGS", "0")), st))
 logits(); up(); torch.cuda.synchronize()
 print(f"masks {total}: logits {timeit(logits):.1f} us, upsample (fill + box) {timeit(up):.1f} us")
