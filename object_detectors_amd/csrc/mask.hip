@@ -5,21 +5,22 @@
 // object_detectors/yolov5_lmi/trt/yolov5_trt.py:373-415).  Semantics: oracle/masks.py.
 //
 // Kernels
-//  mask_logits_rows_kernel  logits[slot][y][x] = sum_k coef[slot][k] * proto[b][k][y][x], only for the rows
-//                        of the letterbox crop window that lie under the survivor's box, as a k-ordered
+//  mask_logits_rows_kernel  logits[slot][y][x] = sum_k coef[slot][k] * proto[b][k][y][x], only for the rows and
+//                        columns of the letterbox crop window that the survivor's box can read, as a k-ordered
 //                        fmaf chain on the vector ALU (v_pk_fma_f32); proto is read once.
 //  mask_gemm_kernel      the same product as dense 32-survivor tiles on the exact-fp32 MFMA
 //                        (v_mfma_f32_32x32x2_f32); kept for odd prototype widths.
 //  The upsample is HBM-write-bound (m*H0*W0 bytes of uint8 per image, ~97 % of them zeros outside the boxes) and
-//  runs as two passes when output rows are whole 16-byte chunks:
+//  runs as two passes:
 //  mask_slot_table_kernel  per slot, the integer pixel ranges of its box.
 //  mask_zero_fill_kernel   zeros for all live slots from ONE workgroup per CU: the write pattern that reaches the
 //                        memset rate (6.4 TB/s; profiles/r01/write_ceiling.md).
 //  mask_box_kernel       the chunks that meet a box: bilinear (align_corners=False) -> box crop -> `> 0`
-//                        from logits rows staged in LDS, 16 bytes per lane per store.
+//                        from logits rows staged in LDS, 16 bytes per lane per store (rows that are not whole
+//                        16-byte chunks: the same stores at whatever address, the row's last chunk pixel by pixel).
 //  mask_upsample_kernel  the same result in one pass (per survivor, per strip of output rows, zeros included),
-//                        for row lengths that are not whole chunks and for tiny frames (h0 + w0 <= 128, where aten
-//                        interpolates with its 4-weight kernel); LMI_MASK_UPSAMPLE_SINGLE selects it for every shape.
+//                        for tiny frames (h0 + w0 <= 128, where aten interpolates with its 4-weight kernel);
+//                        LMI_MASK_UPSAMPLE_SINGLE selects it for every shape.
 // Every kernel takes the geometry per image (MaskBatch): a batch of differently sized originals
 // (object_detectors/yolov8_lmi/model.py:215-236 loops over them) is one launch, masks packed back to back.
 #include <mutex>
@@ -398,8 +399,11 @@ struct MaskOut<uint8_t> {
     asm("v_med3_i32 %0, %1, 0, 1" : "=v"(r) : "v"(v));
     return r;
   }
-  static __device__ __forceinline__ void emit_nt(uint8_t *p, const f2v (&v)[8], uint32_t allow) {
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  typedef u4 u4_anywhere __attribute__((aligned(1)));
+  // mode 0: p is 16-byte aligned; 1: any address (rows that are not whole chunks; the target runs in unaligned-access
+  // mode, one store instruction either way); 2: only the first n pixels, one by one (the row ends inside the chunk)
+  static __device__ __forceinline__ void emit_nt(uint8_t *p, const f2v (&v)[8], uint32_t allow, int mode = 0, int n = 16) {
     uint32_t w[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -412,7 +416,13 @@ struct MaskOut<uint8_t> {
       w[q] = d & m;
     }
     u4 o = {w[0], w[1], w[2], w[3]};
-    __builtin_nontemporal_store(o, reinterpret_cast<u4 *>(p));
+    if (mode == 0) {
+      __builtin_nontemporal_store(o, reinterpret_cast<u4 *>(p));
+    } else if (mode == 1) {
+      __builtin_nontemporal_store(o, reinterpret_cast<u4_anywhere *>(p));
+    } else {
+      for (int k = 0; k < n; ++k) p[k] = (uint8_t)((w[k >> 2] >> (8 * (k & 3))) & 0xffu);
+    }
   }
 };
 template <>
@@ -428,13 +438,23 @@ struct MaskOut<float> {
   }
   static __device__ __forceinline__ void store1(float *p, bool on) { *p = on ? 1.0f : 0.0f; }
   typedef float f2v __attribute__((ext_vector_type(2)));
-  static __device__ __forceinline__ void emit_nt(float *p, const f2v (&v)[2], uint32_t allow) {
+  static __device__ __forceinline__ void emit_nt(float *p, const f2v (&v)[2], uint32_t allow, int mode = 0, int n = 4) {
     uint32_t bits = 0;
     if (v[0].x > 0.0f) bits |= 1u;
     if (v[0].y > 0.0f) bits |= 2u;
     if (v[1].x > 0.0f) bits |= 4u;
     if (v[1].y > 0.0f) bits |= 8u;
-    store_vec_nt(p, bits & allow);
+    bits &= allow;
+    if (mode == 0) {
+      store_vec_nt(p, bits);
+    } else if (mode == 1) {   // 4-byte aligned, as every float is
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      typedef f4 f4_anywhere __attribute__((aligned(4)));
+      f4 t = {(bits & 1u) ? 1.f : 0.f, (bits & 2u) ? 1.f : 0.f, (bits & 4u) ? 1.f : 0.f, (bits & 8u) ? 1.f : 0.f};
+      __builtin_nontemporal_store(t, reinterpret_cast<f4_anywhere *>(p));
+    } else {
+      for (int k = 0; k < n; ++k) p[k] = ((bits >> k) & 1u) ? 1.0f : 0.0f;
+    }
   }
 };
 
@@ -456,17 +476,18 @@ __global__ __launch_bounds__(256) void mask_slot_table_kernel(GemmParams G) {
 // of instructions: no box test here -- mask_upsample_kernel (box_only) overwrites the few per cent of chunks that
 // meet a box afterwards.
 __global__ __launch_bounds__(256) void mask_zero_fill_kernel(const int *__restrict__ slot_base, int batch, long long capacity,
-                                                            long long chunks_per_slot, long long ragged_chunks, uint4 *__restrict__ out,
+                                                            long long bytes_per_slot, long long ragged_bytes, uint4 *__restrict__ out,
                                                             int *__restrict__ overflow) {
-  long long n = ragged_chunks;   // ragged originals: the host laid the masks out and knows where they end
-  if (ragged_chunks < 0) {
+  long long nbytes = ragged_bytes;   // ragged originals: the host laid the masks out and knows where they end
+  if (ragged_bytes < 0) {
     const long long total_all = slot_base[batch];
     if (blockIdx.x == 0 && threadIdx.x == 0 && overflow) *overflow = total_all > capacity ? (int)(total_all - capacity) : 0;
     const long long total = total_all < capacity ? total_all : capacity;
-    n = total * chunks_per_slot;
+    nbytes = total * bytes_per_slot;
   } else if (blockIdx.x == 0 && threadIdx.x == 0 && overflow) {
     *overflow = 0;
   }
+  const long long n = nbytes >> 4;   // whole 16-byte chunks; frames whose rows are not whole chunks may leave a tail
   const long long stride = (long long)gridDim.x * 256;
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
   const u4 zero = {0u, 0u, 0u, 0u};
@@ -474,13 +495,16 @@ __global__ __launch_bounds__(256) void mask_zero_fill_kernel(const int *__restri
   for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n; g += stride) {
     __builtin_nontemporal_store(zero, o + g);   // plain stores run as fast here but leave write-backs that slow the next kernels
   }
+  if (blockIdx.x == gridDim.x - 1 && (long long)threadIdx.x < (nbytes & 15))
+    reinterpret_cast<unsigned char *>(out)[(n << 4) + threadIdx.x] = 0;
 }
 
 // Second pass of the split path: the chunks that meet a slot's box, and nothing else.  grid: x = row strips, y = slot.
 // Every lane owns one 16-byte chunk column of the box and walks down the strip's box rows, so the horizontal
 // weights of its pixels are computed once and all lanes of a wave have work (a lane-per-chunk sweep over whole rows
 // leaves ~3/4 of the lanes idle on boxes ~1/7 of the frame wide).  Same arithmetic as mask_upsample_kernel.
-template <typename OutT>
+// CHUNKED: every image's rows and mask starts are whole 16-byte chunks (the common case: aligned stores only).
+template <typename OutT, bool CHUNKED>
 __global__ __launch_bounds__(256, 4) void mask_box_kernel(UpParams U) {   // 4 waves per SIMD: at most 128 VGPRs
   using MO = MaskOut<OutT>;
   constexpr int PX = MO::PX;
@@ -513,6 +537,9 @@ __global__ __launch_bounds__(256, 4) void mask_box_kernel(UpParams U) {   // 4 w
     ca = ca / kBlock * kBlock;
     cb = (cb + kBlock - 1) / kBlock * kBlock;
   }
+  // Rows (or mask starts) that are not whole 16-byte chunks: the chunk columns stay relative to the row start, the
+  // stores go to whatever address that gives, and a chunk the row ends in is written pixel by pixel.
+  const bool chunked = CHUNKED || ((W0 % PX) == 0 && (off % PX) == 0);
   // Staged: the logits rows this strip's box rows read, and of those only the columns its chunk columns read, plus
   // one more column (the last logits column repeated past the right border): the right-hand tap of a pixel is then
   // always the next float -- ix1 == ix0 only at the right border, where both taps read the last column -- and one
@@ -598,7 +625,10 @@ __global__ __launch_bounds__(256, 4) void mask_box_kernel(UpParams U) {   // 4 w
 #pragma unroll
       for (int h = 0; h < PX / 2; ++h)   // aten: fma(upper, w_upper, lower * w_lower), two pixels per packed instruction (each half rounds like the scalar form)
         v[h] = __builtin_elementwise_fma(tu[h], w0v, tl[h] * w1v);
-      MO::emit_nt(out + (size_t)y * W0 + x0, v, xmask);
+      OutT *o = out + (size_t)y * W0 + x0;
+      if (CHUNKED || chunked) MO::emit_nt(o, v, xmask);
+      else if (x0 + PX <= W0) MO::emit_nt(o, v, xmask, 1);
+      else MO::emit_nt(o, v, xmask, 2, W0 - x0);
     }
   }
 }
@@ -720,7 +750,8 @@ struct MaskCall {
   int max_ww;          // widest crop window
   int max_wh;          // tallest crop window
   double max_ratio;    // largest wh / h0: logits rows per output row
-  bool rows_chunked;   // every image: rows and mask starts are whole 16-byte chunks, h0 + w0 > 128
+  bool separable;      // every image: h0 + w0 > 128 (aten's separable kernel; smaller frames take its 4-weight form)
+  bool chunked;        // every image: rows and mask starts are whole 16-byte chunks
   long long end_elems; // ragged: one past the last mask element
 };
 
@@ -732,7 +763,7 @@ int mask_check_common(const char *fn, int batch, int nm, int mh, int mw, int h0,
   LMI_REQUIRE(capacity_masks > 0 && capacity_masks <= 65535, LMI_ERR_LIMIT, "%s: capacity_masks %lld not in 1..65535", fn, (long long)capacity_masks);
   LMI_REQUIRE((images_host == nullptr) == (images_dev == nullptr), LMI_ERR_BAD_ARG, "%s: images_host and images_dev go together", fn);
   C.M.images = images_dev;
-  C.max_h0 = 0; C.max_ww = 0; C.max_wh = 0; C.max_ratio = 0.0; C.rows_chunked = true; C.end_elems = 0;
+  C.max_h0 = 0; C.max_ww = 0; C.max_wh = 0; C.max_ratio = 0.0; C.separable = true; C.chunked = true; C.end_elems = 0;
   const int n = images_host ? batch : 1;
   for (int b = 0; b < n; ++b) {
     const int ih = images_host ? images_host[b].h0 : h0, iw = images_host ? images_host[b].w0 : w0;
@@ -747,15 +778,14 @@ int mask_check_common(const char *fn, int batch, int nm, int mh, int mw, int h0,
     if (wh > C.max_wh) C.max_wh = wh;
     const double ratio = (double)wh / (double)ih;
     if (ratio > C.max_ratio) C.max_ratio = ratio;
-    bool ok = (iw % px) == 0 && ih + iw > 128;
     if (images_host) {
       const lmi_mask_image &im = images_host[b];
       LMI_REQUIRE(im.n_masks >= 0 && im.out_offset >= 0, LMI_ERR_BAD_ARG, "%s: image %d: negative mask count / offset", fn, b);
-      ok = ok && (im.out_offset % px) == 0;
       const long long end = (long long)im.out_offset + (long long)im.n_masks * ih * iw;
       if (im.n_masks > 0 && end > C.end_elems) C.end_elems = end;
     }
-    C.rows_chunked = C.rows_chunked && ok;
+    C.separable = C.separable && ih + iw > 128;
+    C.chunked = C.chunked && (iw % px) == 0 && (!images_host || (images_host[b].out_offset % px) == 0);
   }
   if (images_host) { C.M.g.mh = mh; C.M.g.mw = mw; }
   return LMI_OK;
@@ -844,21 +874,27 @@ int lmi_mask_upsample_ex(void *workspace, int batch, int nm, int mh, int mw, con
   U.rows_per_block = 0; U.lds_rows = 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
-  // Split path (rows are whole 16-byte chunks): zeros for every live slot at the memset rate -- one workgroup per
+  // Split path: zeros for every live slot at the memset rate -- one workgroup per
   // CU, the compact write window -- then mask_box_kernel overwrites only the chunks that meet a box (ALU-bound, not
   // store-bound: tall strips, so that a lane's horizontal taps serve many rows).
-  if (C.rows_chunked && !(flags & LMI_MASK_UPSAMPLE_SINGLE)) {
-    const long long ragged_chunks = images_host ? (C.end_elems + px - 1) / px : -1;
+  if (C.separable && !(flags & LMI_MASK_UPSAMPLE_SINGLE)) {
+    const long long esz = out_dtype == LMI_U8 ? 1 : 4;
+    const long long ragged_bytes = images_host ? C.end_elems * esz : -1;
     hipLaunchKernelGGL(mask_zero_fill_kernel, dim3(device_cu_count()), dim3(256), 0, s, slot_base, batch, (long long)capacity_masks,
-                       (long long)C.M.g.h0 * (C.M.g.w0 / px), ragged_chunks, reinterpret_cast<uint4 *>(out_masks), overflow);
+                       (long long)C.M.g.h0 * C.M.g.w0 * esz, ragged_bytes, reinterpret_cast<uint4 *>(out_masks), overflow);
     rc = lmi_check_launch("mask_zero_fill_kernel");
     if (rc) return rc;
     rc = up_strip(C, U, 256, 1);
     if (rc) return rc;
     const size_t lds = (size_t)U.lds_rows * (C.max_ww + 1) * sizeof(float);
     dim3 grid((C.max_h0 + U.rows_per_block - 1) / U.rows_per_block, (unsigned)capacity_masks);
-    if (out_dtype == LMI_U8) hipLaunchKernelGGL(mask_box_kernel<uint8_t>, grid, dim3(256), lds, s, U);
-    else hipLaunchKernelGGL(mask_box_kernel<float>, grid, dim3(256), lds, s, U);
+    if (out_dtype == LMI_U8) {
+      if (C.chunked) hipLaunchKernelGGL((mask_box_kernel<uint8_t, true>), grid, dim3(256), lds, s, U);
+      else hipLaunchKernelGGL((mask_box_kernel<uint8_t, false>), grid, dim3(256), lds, s, U);
+    } else {
+      if (C.chunked) hipLaunchKernelGGL((mask_box_kernel<float, true>), grid, dim3(256), lds, s, U);
+      else hipLaunchKernelGGL((mask_box_kernel<float, false>), grid, dim3(256), lds, s, U);
+    }
     return lmi_check_launch("mask_box_kernel");
   }
   rc = up_strip(C, U, 16, 0);

@@ -237,7 +237,7 @@ def test_nms_halves_equal_the_one_call_form(ops, rotated):
 
 
 def test_mask_upsample_two_pass_form_equals_single_pass_and_oracle(ops):
-    """Rows of whole 16-byte chunks take the zero-fill + box-pass form of lmi_mask_upsample: against the one-kernel
+    """Frames with h0 + w0 > 128 take the zero-fill + box-pass form of lmi_mask_upsample: against the one-kernel
     form (flag LMI_MASK_UPSAMPLE_SINGLE) bit for bit and against the oracle, on the layouts that stress
     it: full-frame and out-of-frame boxes, empty boxes, > 256 chunk columns (fp32, 4K-wide rows), frames smaller
     than the prototype window, and a buffer with more capacity than survivors (dead slots stay untouched)."""
@@ -248,6 +248,8 @@ def test_mask_upsample_two_pass_form_equals_single_pass_and_oracle(ops):
         (40, 40, 270, 480, torch.uint8), (40, 40, 270, 480, torch.float32), (80, 80, 1080, 1920, torch.uint8),
         (40, 40, 135, 3840, torch.float32), (40, 52, 33, 48, torch.uint8), (80, 80, 2160, 3840, torch.uint8),
         (160, 160, 64, 96, torch.uint8), (25, 40, 200, 16, torch.uint8), (20, 20, 17, 4, torch.float32),
+        # rows that are not whole 16-byte chunks: stores at any address, the row's last chunk pixel by pixel, a fill with a tail
+        (40, 40, 270, 481, torch.uint8), (80, 80, 375, 500, torch.uint8), (40, 40, 133, 203, torch.float32), (40, 40, 129, 7, torch.uint8),
     ]
     for ci, (mh, mw, h0, w0, dtype) in enumerate(cases):
         B, max_det = 2, 8

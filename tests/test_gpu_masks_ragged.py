@@ -66,18 +66,26 @@ def test_ragged_batch_equals_per_image_calls_and_oracle(ops, out_dtype):
         assert ref.sum() > 0 and OM.mask_iou(views[b].cpu().numpy(), ref) >= 0.999, b
 
 
-def test_ragged_batch_with_unaligned_widths_takes_the_one_pass_kernel(ops):
+@pytest.mark.parametrize("sizes", [
+    [(375, 500), (101, 67), (480, 640), (60, 60)],     # 500 and 67 are not whole chunks; 60 + 60 <= 128: aten's 4-weight kernel, the one-pass form for the batch
+    [(375, 500), (101, 67), (480, 640), (211, 333)],   # every frame separable: two passes, stores at any address
+])
+def test_ragged_batch_with_unaligned_widths(ops, sizes):
     rng = np.random.default_rng(62)
-    sizes = [(375, 500), (101, 67), (480, 640), (60, 60)]     # 500 and 67 are not whole chunks; 60 + 60 <= 128: aten's 4-weight kernel
     counts = [4, 3, 2, 3]
     B, mh, mw, max_det = len(sizes), 40, 40, 8
     proto = synth.proto(rng, B, 32, mh, mw)
     det, sm, sb = scene(rng, sizes, counts, max_det)
-    for upsample in ("split", "single"):
-        views = ops.process_mask_ragged(dev(proto), dev(det), dev(sm), dev(sb), sizes, counts, torch.uint8, upsample=upsample)
-        for b, ((h0, w0), n) in enumerate(zip(sizes, counts)):
-            ref = OM.process_mask_native(proto[b], det[b, :n, 6:], det[b, :n, :4], (h0, w0))
-            assert OM.mask_iou(views[b].cpu().numpy(), ref) >= 0.999, b
+    both = {}
+    for out_dtype in (torch.uint8, torch.float32):
+        for upsample in ("split", "single"):
+            views = ops.process_mask_ragged(dev(proto), dev(det), dev(sm), dev(sb), sizes, counts, out_dtype, upsample=upsample)
+            both[upsample] = views
+            for b, ((h0, w0), n) in enumerate(zip(sizes, counts)):
+                ref = OM.process_mask_native(proto[b], det[b, :n, 6:], det[b, :n, :4], (h0, w0))
+                assert OM.mask_iou(views[b].cpu().numpy(), ref) >= 0.999, b
+        for a, c in zip(both["split"], both["single"]):
+            assert torch.equal(a, c)
     with pytest.raises(ValueError):
         ops.process_mask_ragged(dev(proto), dev(det), dev(sm), dev(sb), sizes[:2], counts[:2])
     none = ops.process_mask_ragged(dev(proto), dev(det), dev(sm), dev(np.zeros(B + 1, np.int32)), sizes, [0] * B)
