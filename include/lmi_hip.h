@@ -113,7 +113,9 @@ typedef struct lmi_frame {
  * oracle/geometry.py; aten switches between two kernels at new_h + new_w = 128, so does this one, per
  * frame).  LMI_RESIZE_TORCH_BILINEAR_1T is what the same helpers compute when torch runs on exactly ONE thread
  * (torch.set_num_threads(1), OMP_NUM_THREADS=1): aten then takes its 4-weight kernel for every 3-channel frame.
- * workspace is not used (may be NULL).
+ * workspace: as for the cv2 mode -- the tables then hold aten's indices and fp32 weights and the same LDS-staged kernel
+ * runs (as fast as the cv2 mode); NULL or too small a workspace selects a table-free kernel that reads its taps straight
+ * from global memory (2-3 x slower, same result).
  */
 int64_t lmi_letterbox_workspace_bytes(int table_sets, int dst_h, int dst_w);
 int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, int batch,

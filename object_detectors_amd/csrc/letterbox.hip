@@ -41,6 +41,7 @@ struct LbParams {
   int4 *ytab;       // [sets][dst_h]  {source row 0, source row 1 (or -1,-1: border row), b0 | b1 << 16, 0}
   int xw;           // dst_w rounded up to 4
   int torch_one_thread;  // torch flavour: aten's kernel choice on exactly one thread (always the 4-weight form)
+  int torch;             // tables and arithmetic of the torch flavour (aten bilinear on the fp32 cast, truncating cast)
 };
 
 // One axis of OpenCV's INTER_LINEAR table (resize.cpp, cv::hal::resize): see oracle/cv2_resize.py.
@@ -58,6 +59,16 @@ __device__ __forceinline__ void cv_linear_coef(int src_n, int dst_n, int d, bool
   w0 = (int)rintf((1.0f - f) * 2048.0f);
   w1 = (int)rintf(f * 2048.0f);
   s = si;
+}
+
+// aten upsample_bilinear2d (align_corners=False) source index and weights as torch's x86 CPU build computes them
+// (oracle/geometry.py:resize_bilinear): the coordinate is one fused multiply-add, clamped at 0.
+__device__ __forceinline__ void aten_linear_src(float scale, int d, int in_n, int &i0, int &i1, float &l0, float &l1) {
+  float s = fmaxf(fmaf(scale, (float)d + 0.5f, -0.5f), 0.0f);
+  i0 = min((int)s, in_n - 1);
+  i1 = i0 + ((i0 < in_n - 1) ? 1 : 0);
+  l1 = fminf(fmaxf(s - (float)i0, 0.0f), 1.0f);
+  l0 = 1.0f - l1;
 }
 
 __device__ __forceinline__ void frame_of(const LbParams &P, int b, const uint8_t *&src, int &h, int &w, long long &stride,
@@ -85,12 +96,26 @@ __global__ __launch_bounds__(256) void letterbox_tables_kernel(LbParams P) {
   if (i < P.xw) {
     const int dx = i - pad_l;
     int s = -1, a0 = 0, a1 = 0;
-    if (dx >= 0 && dx < new_w && i < P.dst_w) cv_linear_coef(w, new_w, dx, true, s, a0, a1);
+    if (dx >= 0 && dx < new_w && i < P.dst_w) {
+      if (P.torch) {   // {left source pixel, fp32 bits of the right-hand weight}
+        int i1; float l0, l1;
+        aten_linear_src((float)w / (float)new_w, dx, w, s, i1, l0, l1);
+        P.xtab[(size_t)set * P.xw + i] = make_int2(s, __float_as_int(l1));
+        return;
+      }
+      cv_linear_coef(w, new_w, dx, true, s, a0, a1);
+    }
     P.xtab[(size_t)set * P.xw + i] = make_int2(s, (int)((uint32_t)a0 | ((uint32_t)a1 << 16)));
   } else if (i < P.xw + P.dst_h) {
     const int y = i - P.xw;
     const int dy = y - pad_t;
     int r0 = -1, r1 = -1, b0 = 0, b1 = 0;
+    if (dy >= 0 && dy < new_h && P.torch) {   // {upper row, lower row, fp32 bits of the lower row's weight}
+      float l0, l1;
+      aten_linear_src((float)h / (float)new_h, dy, h, r0, r1, l0, l1);
+      P.ytab[(size_t)set * P.dst_h + y] = make_int4(r0, r1, __float_as_int(l1), 0);
+      return;
+    }
     if (dy >= 0 && dy < new_h) {
       int s;
       cv_linear_coef(h, new_h, dy, false, s, b0, b1);
@@ -158,7 +183,10 @@ struct OutTraits<__half> {
 // row tile_y0 + r.  LDS holds only the staged source rows.
 // KF = 16-byte staging loads a lane keeps in flight: as many as a staged row has chunks per lane (4K -> 640: 10), no
 // more -- a load past the row's span is dropped by the range check but still costs its issue slot.
-template <typename OutT, int TW, int TH, int KF>
+// TORCH: the tables hold aten's source indices and fp32 weights, the arithmetic is aten's CPU bilinear on the fp32 cast
+// with a truncating cast back (the reference helpers' resize_image); staging, tiles and stores are
+// the same.
+template <typename OutT, int TW, int TH, int KF, bool TORCH>
 __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
   constexpr int NT = (TW / 4) * TH;
   extern __shared__ __attribute__((aligned(16))) unsigned char rows[];
@@ -185,6 +213,9 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
 
   const int g = tid % (TW / 4), r = tid / (TW / 4);
   const int x0 = x_t0 + 4 * g, y = y_t0 + r;
+  // aten's choice between its two CPU kernels for a 3-channel frame: by output size on >= 2 threads, always the
+  // 4-weight form on one
+  const bool weights4 = TORCH && (P.torch_one_thread || new_h + new_w <= 128);
   const reg_t pv = TR::make(P.pad_value);
 
   // content rectangle clipped to this tile
@@ -242,7 +273,11 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
       // fetched (the lanes then multiply stale LDS bytes by 0).  Exact integer down-scales such as 1080p -> 640x360
       // (fy = 3 dy + 1) need only one source row per output row this way: half the reads.
       const uint32_t bw = (uint32_t)e.z;
-      if (((slot & 1) ? (bw >> 16) : (bw & 0xffffu)) == 0u) row = -1;
+      if constexpr (TORCH) {   // lower row with weight +0.0: t1 * 0 adds nothing (the staged bytes are finite as floats)
+        if ((slot & 1) && bw == 0u) row = -1;
+      } else {
+        if (((slot & 1) ? (bw >> 16) : (bw & 0xffffu)) == 0u) row = -1;
+      }
     }
     if (row >= 0) {
       const uint32_t goff = (uint32_t)((long long)row * stride + span_b0);
@@ -296,7 +331,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
       }
       const uint32_t aw = (uint32_t)xa_[k];
       const int a0 = (int)(aw & 0xffffu), a1 = (int)(aw >> 16);
-      if ((a1 | b1) == 0) {
+      if (TORCH ? (aw | bw) == 0u : (a1 | b1) == 0) {   // torch flavour: both second weights +0.0 -> (int)(float)tap = tap
         // Both second weights are 0 (a0 = b0 = 2048): the fixed-point sum is the left upper tap itself,
         // ((2048 * ((s * 2048) >> 4)) >> 16 + 2) >> 2 = s.  Every pixel of an exact odd reduction (1080p -> 640x360:
         // fx = 3 dx + 1) or of a frame already at model size takes this branch: one tap, no arithmetic.
@@ -324,6 +359,23 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
         const int s10 = (int)((px[1][0] >> (8 * c)) & 0xffu);
         const int s01 = (c == 0) ? (int)(px[0][0] >> 24) : (int)((px[0][1] >> (8 * (c - 1))) & 0xffu);
         const int s11 = (c == 0) ? (int)(px[1][0] >> 24) : (int)((px[1][1] >> (8 * (c - 1))) & 0xffu);
+        if constexpr (TORCH) {
+          // aten: at the right border both horizontal taps are the last pixel; a lower row that was not staged has
+          // weight 0 and whatever finite bytes the LDS holds
+          const bool edge = s >= w - 1;
+          const float lx1 = __uint_as_float(aw), lx0 = 1.0f - lx1, ly1 = __uint_as_float(bw), ly0 = 1.0f - ly1;
+          const float i00 = (float)s00, i01 = (float)(edge ? s00 : s01), i10 = (float)s10, i11 = (float)(edge ? s10 : s11);
+          float v;
+          if (weights4) {
+            const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+            v = fmaf(w11, i11, fmaf(w10, i10, fmaf(w00, i00, w01 * i01)));
+          } else {
+            const float t0 = fmaf(i00, lx0, i01 * lx1), t1 = fmaf(i10, lx0, i11 * lx1);
+            v = fmaf(t0, ly0, t1 * ly1);
+          }
+          out[c][k] = TR::make((int)v);   // `.to(uint8)`: truncation (the value lies in [0, 255.00002])
+          continue;
+        }
         const int h0 = s00 * a0 + s01 * a1;
         const int h1 = s10 * a0 + s11 * a1;
         const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
@@ -396,14 +448,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restri
 // fma(scale, d + 0.5, -0.5) clamped at 0; then the per-pixel 4-weight kernel aten runs when out_h + out_w <= 128,
 // else its separable kernel (horizontal pairs, then vertical, each fma(a, wa, b*wb)).
 // One lane = 4 output pixels x 3 channels; taps are read straight from L2/HBM (12 bytes per tap pair).
-__device__ __forceinline__ void aten_linear_src(float scale, int d, int in_n, int &i0, int &i1, float &l0, float &l1) {
-  float s = fmaxf(fmaf(scale, (float)d + 0.5f, -0.5f), 0.0f);
-  i0 = min((int)s, in_n - 1);
-  i1 = i0 + ((i0 < in_n - 1) ? 1 : 0);
-  l1 = fminf(fmaxf(s - (float)i0, 0.0f), 1.0f);
-  l0 = 1.0f - l1;
-}
-
 template <typename OutT>
 __global__ __launch_bounds__(256) void letterbox_torch_kernel(LbParams P) {
   using TR = OutTraits<OutT>;
@@ -503,7 +547,7 @@ TabLayout tab_layout(int sets, int dst_h, int dst_w) {
   return L;
 }
 
-template <typename OutT>
+template <typename OutT, bool TORCH>
 int launch_letterbox(const LbParams &P0, int batch, int sets, int max_pitch128, int max_pitch32, void *workspace,
                      int64_t workspace_bytes, hipStream_t stream) {
   LbParams P = P0;
@@ -512,6 +556,7 @@ int launch_letterbox(const LbParams &P0, int batch, int sets, int max_pitch128, 
   LMI_REQUIRE(workspace_bytes >= (int64_t)L.total, LMI_ERR_WORKSPACE, "lmi_letterbox_u8: workspace %lld < %lld bytes",
               (long long)workspace_bytes, (long long)L.total);
   P.xw = L.xw;
+  P.torch = TORCH ? 1 : 0;
   P.xtab = reinterpret_cast<int2 *>(workspace);
   P.ytab = reinterpret_cast<int4 *>(reinterpret_cast<unsigned char *>(workspace) + L.off_y);
   hipLaunchKernelGGL(letterbox_tables_kernel, dim3((L.xw + P.dst_h + 255) / 256, sets), dim3(256), 0, stream, P);
@@ -525,16 +570,16 @@ int launch_letterbox(const LbParams &P0, int batch, int sets, int max_pitch128, 
     P.tiles_y = (P.dst_h + kTH - 1) / kTH;
     dim3 grid(P.tiles_x * P.tiles_y, batch);
     // chunks per lane of a staged row: pitch / 16 bytes over the 16 lanes that share the row
-    if (P.pitch > 8 * 256) hipLaunchKernelGGL((letterbox_kernel<OutT, 128, kTH, 12>), grid, dim3(32 * kTH), lds_bytes_for(P.pitch), stream, P);
-    else if (P.pitch > 4 * 256) hipLaunchKernelGGL((letterbox_kernel<OutT, 128, kTH, 8>), grid, dim3(32 * kTH), lds_bytes_for(P.pitch), stream, P);
-    else hipLaunchKernelGGL((letterbox_kernel<OutT, 128, kTH, 4>), grid, dim3(32 * kTH), lds_bytes_for(P.pitch), stream, P);
+    if (P.pitch > 8 * 256) hipLaunchKernelGGL((letterbox_kernel<OutT, 128, kTH, 12, TORCH>), grid, dim3(32 * kTH), lds_bytes_for(P.pitch), stream, P);
+    else if (P.pitch > 4 * 256) hipLaunchKernelGGL((letterbox_kernel<OutT, 128, kTH, 8, TORCH>), grid, dim3(32 * kTH), lds_bytes_for(P.pitch), stream, P);
+    else hipLaunchKernelGGL((letterbox_kernel<OutT, 128, kTH, 4, TORCH>), grid, dim3(32 * kTH), lds_bytes_for(P.pitch), stream, P);
   } else if (lds_bytes_for(max_pitch32) <= 2 * kMaxLds) {
     P.pitch = max_pitch32;
     P.tiles_x = (P.dst_w + 31) / 32;
     P.tiles_y = (P.dst_h + kTH - 1) / kTH;
     dim3 grid(P.tiles_x * P.tiles_y, batch);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(letterbox_kernel<OutT, 32, kTH, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)kMaxLds);
-    hipLaunchKernelGGL((letterbox_kernel<OutT, 32, kTH, 4>), grid, dim3(8 * kTH), lds_bytes_for(P.pitch), stream, P);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(letterbox_kernel<OutT, 32, kTH, 4, TORCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)kMaxLds);
+    hipLaunchKernelGGL((letterbox_kernel<OutT, 32, kTH, 4, TORCH>), grid, dim3(8 * kTH), lds_bytes_for(P.pitch), stream, P);
   } else {
     lmi_set_error("lmi_letterbox_u8: down-scale factor too large for the LDS row tiles");
     return LMI_ERR_LIMIT;
@@ -595,10 +640,16 @@ int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, 
   P.dst = dst; P.dst_h = dst_h; P.dst_w = dst_w; P.pad_value = pad_value; P.swap_rb = swap_rb ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   P.torch_one_thread = mode == LMI_RESIZE_TORCH_BILINEAR_1T ? 1 : 0;
-  if (mode != LMI_RESIZE_CV2_LINEAR)   // no tables: workspace is not used
-    return dst_dtype == LMI_F32 ? launch_letterbox_torch<float>(P, batch, s) : launch_letterbox_torch<__half>(P, batch, s);
-  return dst_dtype == LMI_F32 ? launch_letterbox<float>(P, batch, batch, p128, p32, workspace, workspace_bytes, s)
-                              : launch_letterbox<__half>(P, batch, batch, p128, p32, workspace, workspace_bytes, s);
+  if (mode != LMI_RESIZE_CV2_LINEAR) {
+    // with a workspace for the tables: the LDS-staged kernel (249 -> ~100 us per 64 x 1080p); without one, the
+    // table-free kernel that reads its taps straight from global memory (the entry's contract before r02)
+    if (workspace == nullptr || workspace_bytes < lmi_letterbox_workspace_bytes(batch, dst_h, dst_w))
+      return dst_dtype == LMI_F32 ? launch_letterbox_torch<float>(P, batch, s) : launch_letterbox_torch<__half>(P, batch, s);
+    return dst_dtype == LMI_F32 ? launch_letterbox<float, true>(P, batch, batch, p128, p32, workspace, workspace_bytes, s)
+                                : launch_letterbox<__half, true>(P, batch, batch, p128, p32, workspace, workspace_bytes, s);
+  }
+  return dst_dtype == LMI_F32 ? launch_letterbox<float, false>(P, batch, batch, p128, p32, workspace, workspace_bytes, s)
+                              : launch_letterbox<__half, false>(P, batch, batch, p128, p32, workspace, workspace_bytes, s);
 }
 
 int lmi_letterbox_u8_uniform(const void *src, int batch, int h, int w, int64_t row_stride, int64_t image_stride,
@@ -627,8 +678,8 @@ int lmi_letterbox_u8_uniform(const void *src, int batch, int h, int w, int64_t r
   P.dst = dst; P.dst_h = dst_h; P.dst_w = dst_w; P.pad_value = pad_value; P.swap_rb = swap_rb ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int p128 = lds_pitch_for(w, g[0], 128), p32 = lds_pitch_for(w, g[0], 32);
-  return dst_dtype == LMI_F32 ? launch_letterbox<float>(P, batch, 1, p128, p32, workspace, workspace_bytes, s)
-                              : launch_letterbox<__half>(P, batch, 1, p128, p32, workspace, workspace_bytes, s);
+  return dst_dtype == LMI_F32 ? launch_letterbox<float, false>(P, batch, 1, p128, p32, workspace, workspace_bytes, s)
+                              : launch_letterbox<__half, false>(P, batch, 1, p128, p32, workspace, workspace_bytes, s);
 }
 
 int lmi_preprocess_u8(const void *src, int h, int w, int c, int64_t row_stride, void *dst, int dst_dtype, void *stream) {

@@ -21,3 +21,12 @@ for (h,w,S,B) in [(1080,1920,640,64),(2160,3840,640,64),(640,640,640,64),(1080,1
         ops.letterbox(fs[k[0]],(S,S),out=o,pad_value=114,swap_rb=True)
     print(f"{B} x {h}x{w} -> {S}: {timeit(rot):.1f} us", flush=True)
     del fs
+print("torch flavour (resize_image + fit_im_to_size arithmetic):")
+for (h,w,S,B) in [(1080,1920,640,64),(2160,3840,640,64),(480,640,640,64)]:
+    fs=[list(torch.randint(0,256,(B,h,w,3),dtype=torch.uint8,device='cuda').unbind(0)) for _ in range(3)]
+    k=[0]
+    def rot():
+        k[0]=(k[0]+1)%3
+        ops.letterbox(fs[k[0]],(S,S),pad_value=0,swap_rb=False,mode="torch")
+    print(f"{B} x {h}x{w} -> {S}: {timeit(rot):.1f} us", flush=True)
+    del fs
