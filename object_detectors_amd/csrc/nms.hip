@@ -310,6 +310,8 @@ __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay
 // when they fit the LDS buffer, else in gkeys[0..P2) (through the scratch copy gtmp), padded with zeros.
 // scr: 2 * 256 + 32 ints of LDS.
 constexpr int kGatherChunk = 256;   // segments whose prefix is held in LDS at a time
+constexpr int kRotQueue = 128;      // rotated NMS: near pairs a wave queues before it evaluates 64 of them
+constexpr size_t kGatherLds = sizeof(int) * (2 * kGatherChunk + 32);   // gather_candidates' scratch, behind the box buffer
 
 __device__ int gather_candidates(const int *__restrict__ cnt, int nblk, int seg, int A, int lds_keys, uint64_t *lkeys, uint64_t *gkeys,
                                  uint64_t *gtmp, int *scr, int &P2, bool &in_lds) {
@@ -660,7 +662,7 @@ struct SortNmsParams {
   int *out_anchor;
   int lds_keys;  // capacity (keys) of the LDS sort buffer
   int lbox_off;  // byte offset of the LDS box buffer (lds_keys float4)
-  float2 *scd;   // rotated: covariance c and determinant per sorted candidate (global copy)
+  float2 *scd;   // rotated: covariance c and reach per sorted candidate (global copy)
 };
 
 // Fused per-image half of `lmi_finalize_detections` (finalize_boxes_kernel is the stand-alone form): the per-class
@@ -920,7 +922,7 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_rotated(SortNmsParams S
   int *kpos = reinterpret_cast<int *>(smem + (size_t)S.lds_keys * 8);
   int *wcnt = kpos + md;  // 16 wave counts + running total
   float4 *lbox = reinterpret_cast<float4 *>(smem + S.lbox_off);   // x + off, y + off, a, b
-  float2 *lcd = reinterpret_cast<float2 *>(lbox + S.lds_keys);     // c, max(ab - c^2, 0)
+  float2 *lcd = reinterpret_cast<float2 *>(lbox + S.lds_keys);     // c, reach
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -953,24 +955,74 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_rotated(SortNmsParams S
     const float cos2 = cs * cs, sin2 = sn * sn;
     const float ca = w2 * cos2 + h2 * sin2, cb = w2 * sin2 + h2 * cos2, cc = ((w2 - h2) * cs) * sn;
     box[i] = make_float4(x + off, y + off, ca, cb);
-    cd[i] = make_float2(cc, fmaxf(ca * cb - cc * cc, 0.0f));
+    // `reach`: a + b (the trace of the covariance) for a well-conditioned box, +inf otherwise -- see the pair loop
+    const float d = fmaxf(ca * cb - cc * cc, 0.0f), tr = ca + cb;
+    cd[i] = make_float2(cc, (d >= 1e-3f && d >= 1e-4f * (tr * tr)) ? tr : __builtin_inff());
   }
   __syncthreads();
 
-  // column j is dropped unless every earlier (higher-scored) box has probiou < thr; the decision is parked in bit 31
-  // of the key's anchor word (~anchor has it set: anchors < 2^24), cleared = dropped
-  for (int j = tid; j < n_eff; j += kSortThreads) {
-    const float4 bj = box[j];
-    const float2 cj = cd[j];
-    // `ious.triu_(1).max(0) < thr`: the column maximum includes the zeros below the diagonal, so nothing passes thr <= 0
-    bool keep = 0.0f < S.iou_thr;
-    for (int i = 0; i < j; ++i) {
-      const float4 bi = box[i];
-      const float2 ci = cd[i];
-      const float v = probiou(bi.x, bi.y, bi.z, bi.w, ci.x, ci.y, bj.x, bj.y, bj.z, bj.w, cj.x, cj.y);
-      if (!(v < S.iou_thr)) { keep = false; break; }
+  // Column j is dropped unless every earlier (higher-scored) box has probiou < thr; the decision is parked in bit 31
+  // of the key's anchor word (~anchor has it set: anchors < 2^24), cleared = dropped.
+  // `ious.triu_(1).max(0) < thr`: the column maximum includes the zeros below the diagonal, so nothing passes thr <= 0.
+  //
+  // Far pairs never see the formula (three IEEE divisions, log, exp, two square roots: ~250 instructions).  For two
+  // well-conditioned boxes (det >= 1e-4 trace^2 each, so the summed covariance's determinant is far above fp32
+  // rounding and above the formula's eps) the distance terms obey t1 + t2 = d'S^-1 d / 4 >= |d|^2 / (4 trace(S)),
+  // and t3 >= log(1/2)/2: with |d|^2 > 160 trace(S) the Bhattacharyya distance exceeds 37, exp(-bd) vanishes
+  // against the eps under the root and probiou <= 0 < thr -- the full evaluation would say "no hit" too.  Boxes of
+  // different classes sit 7680 px apart, so this is nearly every pair; a degenerate box (reach = inf) never takes
+  // the shortcut.  The determinant term d is recomputed from a, b, c exactly as it was formed.
+  //
+  // A wave owns every 16th column and scans its rows 64 at a time with the cheap test; the near pairs go into the
+  // wave's queue in LDS and are evaluated 64 at a time, every lane busy with the formula (lane = column, rows walked
+  // serially, ran the formula for the whole wave whenever any lane needed it: 4-10 x slower).
+  if (!(0.0f < S.iou_thr)) {
+    for (int j = tid; j < n_eff; j += kSortThreads) keys[j] &= ~(1ull << 31);
+  } else {
+    uint32_t *queue = reinterpret_cast<uint32_t *>(smem + S.scr_off + kGatherLds) + wave * kRotQueue;
+    uint32_t *key_lo = reinterpret_cast<uint32_t *>(keys);   // little endian: the anchor word of key j is key_lo[2 j]
+    int qn = 0;   // queued pairs (wave-uniform)
+    auto evaluate = [&](int cnt) {
+      if (lane < cnt) {
+        const uint32_t pr = queue[lane];
+        const int i = (int)(pr & 0xffffu), j = (int)(pr >> 16);
+        const float4 bi = box[i], bj = box[j];
+        const float2 ci = cd[i], cj = cd[j];
+        const float di = fmaxf(bi.z * bi.w - ci.x * ci.x, 0.0f), dj = fmaxf(bj.z * bj.w - cj.x * cj.x, 0.0f);
+        const float v = probiou(bi.x, bi.y, bi.z, bi.w, ci.x, di, bj.x, bj.y, bj.z, bj.w, cj.x, dj);
+        if (!(v < S.iou_thr)) atomicAnd(key_lo + 2 * j, 0x7fffffffu);
+      }
+    };
+    for (int j = wave; j < n_eff; j += kSortThreads / 64) {
+      if (!(key_lo[2 * j] >> 31)) continue;   // dropped already by a pair evaluated earlier (a drop is final)
+      const float4 bj = box[j];
+      const float rj = cd[j].y;
+      for (int i0 = 0; i0 < j; i0 += 64) {
+        const int i = i0 + lane;
+        bool near = false;
+        if (i < j) {
+          const float4 bi = box[i];
+          const float dx = bi.x - bj.x, dy = bi.y - bj.y;
+          near = !(dx * dx + dy * dy > 160.0f * (cd[i].y + rj));
+        }
+        const uint64_t m = __ballot(near);
+        if (m == 0) continue;
+        if (near) queue[qn + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)i | ((uint32_t)j << 16);
+        qn += __builtin_popcountll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (qn >= 64) {
+          evaluate(64);
+          __builtin_amdgcn_wave_barrier();
+          const uint32_t t = lane < qn - 64 ? queue[64 + lane] : 0u;
+          __builtin_amdgcn_wave_barrier();
+          if (lane < qn - 64) queue[lane] = t;
+          __builtin_amdgcn_wave_barrier();
+          qn -= 64;
+        }
+      }
     }
-    if (!keep) keys[j] &= ~(1ull << 31);
+    __builtin_amdgcn_wave_barrier();
+    evaluate(qn);
   }
   if (tid == 0) wcnt[16] = 0;
   __syncthreads();
@@ -1200,9 +1252,9 @@ constexpr size_t nms_lds_small(int lds_keys, int max_det) {
   return (size_t)lds_keys * 8 + 4 * 6 * (size_t)((max_det + 1) & ~1) + 64 * 8 + 64 * 4 + 16;
 }
 constexpr size_t nms_lds_rot_head(int lds_keys, int max_det) { return (size_t)lds_keys * 8 + 4 * (size_t)((max_det + 1) & ~1) + 4 * 17 + 16; }
-constexpr size_t kGatherLds = sizeof(int) * (2 * kGatherChunk + 32);   // gather_candidates' scratch, behind the box buffer
 constexpr size_t kNmsLdsMax = ((nms_lds_small(kSortLdsCap, LMI_MAX_DET_CAP) + 15) & ~(size_t)15) + (size_t)kSortLdsCap * 16 + kGatherLds;
-constexpr size_t kNmsLdsRotMax = ((nms_lds_rot_head(kSortLdsCap, LMI_MAX_DET_CAP) + 15) & ~(size_t)15) + (size_t)kSortLdsCap * (16 + 8) + kGatherLds;
+constexpr size_t kRotQueueLds = (size_t)(kSortThreads / 64) * kRotQueue * 4;
+constexpr size_t kNmsLdsRotMax = ((nms_lds_rot_head(kSortLdsCap, LMI_MAX_DET_CAP) + 15) & ~(size_t)15) + (size_t)kSortLdsCap * (16 + 8) + kGatherLds + kRotQueueLds;
 static_assert(kNmsLdsMax <= 160 * 1024 && kNmsLdsRotMax <= 160 * 1024, "sort kernels must fit the 160 KiB LDS of a gfx950 CU");
 
 static int nms_device_state(NmsDeviceState **out) {
@@ -1340,7 +1392,7 @@ static int nms_suppress(const NmsCall &C, const void *pred, int batch, int nc, i
     LMI_REQUIRE(nm >= 1, LMI_ERR_BAD_ARG, "lmi_nms_v8_rotated: the angle must be the last of nm >= 1 extra channels");
     S.lbox_off = (int)((nms_lds_rot_head(S.lds_keys, max_det) + 15) & ~(size_t)15);
     S.scr_off = (int)((size_t)S.lbox_off + (size_t)S.lds_keys * (16 + 8));
-    const size_t lds_rot = (size_t)S.scr_off + kGatherLds;
+    const size_t lds_rot = (size_t)S.scr_off + kGatherLds + kRotQueueLds;
     if (C.half) hipLaunchKernelGGL(nms_sort_rotated<__half>, dim3(batch), dim3(kSortThreads), lds_rot, C.s, S);
     else hipLaunchKernelGGL(nms_sort_rotated<float>, dim3(batch), dim3(kSortThreads), lds_rot, C.s, S);
     return lmi_check_launch("nms_sort_rotated");
