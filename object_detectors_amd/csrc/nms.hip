@@ -909,7 +909,7 @@ __device__ __forceinline__ float probiou(float x1, float y1, float a1, float b1,
   const float t2 = (((sc * (x2 - x1)) * (y1 - y2)) / den) * 0.5f;
   const float t3 = logf(det / (4.0f * sqrtf(d1 * d2) + eps) + eps) * 0.5f;
   float bd = t1 + t2 + t3;
-  bd = fminf(fmaxf(bd, eps), 100.0f);
+  bd = bd != bd ? bd : fminf(fmaxf(bd, eps), 100.0f);   // torch.clamp keeps a NaN (then `NaN < thr` is false: a hit), fmaxf would not
   const float hd = sqrtf(1.0f - expf(-bd) + eps);
   return 1.0f - hd;
 }

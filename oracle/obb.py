@@ -91,7 +91,11 @@ def nms_rotated(boxes: np.ndarray, scores: np.ndarray, threshold: float, max_det
     last = int(pick[-1]) if len(pick) else 0
     if max_det is None or len(pick) < max_det:
         last = n - 1          # every candidate was decided
-    margin = float(np.abs(worst[1:last + 1].astype(np.float64) - float(thr)).min()) if last >= 1 else np.inf
+    # a NaN maximum (the formula's log of a negative determinant ratio, degenerate boxes only) is a drop whatever the
+    # threshold (`NaN < thr` is False in torch too): it has no margin
+    gaps = np.abs(worst[1:last + 1].astype(np.float64) - float(thr)) if last >= 1 else np.zeros(0)
+    gaps = gaps[~np.isnan(gaps)]
+    margin = float(gaps.min()) if len(gaps) else np.inf
     return order[pick], margin
 
 

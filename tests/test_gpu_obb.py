@@ -138,3 +138,36 @@ def test_rotated_nms_more_candidates_than_the_lds_sort_buffer():
         assert len(ra) == 300
         assert int(count[b]) == 300 and anchor[b].cpu().numpy().tolist() == ra.tolist()
         assert np.array_equal(det[b].cpu().numpy(), rows)
+
+
+@pytest.mark.parametrize("agnostic", [False, True])
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_rotated_nms_far_pair_shortcut_is_exact(seed, agnostic):
+    """The rotated pass skips the probiou formula for pairs it can prove to be below any threshold (nms.hip: distance
+    against the covariance traces, well-conditioned boxes only).  Boxes that stress the proof: slivers and needle-thin
+    boxes of aspect 1000:1 (ill-conditioned covariance: they must always take the formula), specks, huge boxes, and
+    ordinary ones spread over several classes -- kept anchors identical to the oracle's dense evaluation of every
+    pair.  (Exactly zero-width boxes and boxes of 1e-3 px are left out: for them the formula's log argument changes
+    sign with the last bit of cos / sin, and numpy, torch-CPU and torch-GPU disagree among themselves.)"""
+    from object_detectors_amd import hip_ops as ops
+    rng = np.random.default_rng(seed)
+    nc, A, size = 6, 768, 640
+    p = np.zeros((1, 4 + nc + 1, A), F32)
+    p[0, 0:2] = rng.uniform(0, size, (2, A))
+    kind = rng.integers(0, 6, A)
+    w = rng.uniform(8, 120, A)
+    h = rng.uniform(8, 120, A)
+    w[kind == 1], h[kind == 1] = 0.05, rng.uniform(5, 50, (kind == 1).sum())         # slivers
+    w[kind == 2], h[kind == 2] = rng.uniform(100, 400, (kind == 2).sum()), rng.uniform(0.1, 0.4, (kind == 2).sum())   # needles
+    w[kind == 3], h[kind == 3] = rng.uniform(1, 3, (kind == 3).sum()), rng.uniform(1, 3, (kind == 3).sum())   # specks
+    w[kind == 4], h[kind == 4] = rng.uniform(400, 900, (kind == 4).sum()), rng.uniform(300, 800, (kind == 4).sum())    # huge
+    p[0, 2], p[0, 3] = w, h
+    p[0, 4:4 + nc] = 0.01
+    score = rng.permutation(A).astype(F32) / A * 0.6 + 0.3                               # distinct, all above conf
+    p[0, 4 + rng.integers(0, nc, A), np.arange(A)] = score
+    p[0, -1] = rng.uniform(-math.pi / 4, 3 * math.pi / 4, A)
+    det, count, anchor = ops.nms_v8(torch.from_numpy(p).cuda(), 0.25, 0.45, agnostic=agnostic, max_det=1000, nc=nc, rotated=True)
+    (rows, ra, margin), = OO.non_max_suppression_rotated(p, 0.25, 0.45, agnostic=agnostic, max_det=1000, nc=nc)
+    assert margin > 2e-5, "seed puts a decision on the threshold: pick another"
+    n = int(count[0])
+    assert 10 < n < A and anchor[0, :n].cpu().tolist() == ra.tolist()
