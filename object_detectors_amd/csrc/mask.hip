@@ -509,6 +509,7 @@ __global__ __launch_bounds__(256, 4) void mask_box_kernel(UpParams U) {   // 4 w
   using MO = MaskOut<OutT>;
   constexpr int PX = MO::PX;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int2 rowtab[256];   // per strip row: {upper | lower << 16 source row, fp32 bits of the lower row's weight}
   float *L = reinterpret_cast<float *>(smem);
 
   const long long slot = blockIdx.y;
@@ -559,6 +560,12 @@ __global__ __launch_bounds__(256, 4) void mask_box_kernel(UpParams U) {   // 4 w
       const int r = idx / ls, c = idx - r * ls;
       L[idx] = src[(size_t)r * mw + min(c_lo + c, ww - 1)];
     }
+    // the vertical source pair and weight of every row of the strip, once (every lane would redo them per row)
+    if ((int)threadIdx.x < rb - ra) {
+      int i0r, i1r; float l0r, l1r;
+      bilinear_src(scale_h, ra + threadIdx.x, wh, i0r, i1r, l0r, l1r);
+      rowtab[threadIdx.x] = make_int2(i0r | (i1r << 16), __float_as_int(l1r));
+    }
     __syncthreads();
   }
 
@@ -601,8 +608,9 @@ __global__ __launch_bounds__(256, 4) void mask_box_kernel(UpParams U) {   // 4 w
     f2 tu[PX / 2], tl[PX / 2];   // upper / lower source row, interpolated horizontally; adjacent pixels paired for packed math
     int cur0 = -1, cur1 = -1;
     for (int y = y_first; y < y_last; y += ystep) {
-      int iy0, iy1; float ly0, ly1;
-      bilinear_src(scale_h, y, wh, iy0, iy1, ly0, ly1);
+      const int2 re = rowtab[y - ra];
+      const int iy0 = re.x & 0xffff, iy1 = re.x >> 16;
+      const float ly1 = __int_as_float(re.y), ly0 = 1.0f - ly1;
       if (iy0 != cur0 || iy1 != cur1) {
         if (iy0 == cur1) {
 #pragma unroll
