@@ -317,6 +317,21 @@ def main():
     per_block = torch.stack(block_all).max(dim=0).values
     elapsed = float(per_block.median())
 
+    # ---- what the last timed step left behind must equal a fresh eager pass over the same batch (guards the graph /
+    # stream plumbing: the buffers are overwritten by every step) ------------------------------------------------------
+    last = (steps - 1) % len(pool)
+    got_lb = pipe.lb_out.clone()
+    got_det, got_count = pipe.nms_out[0].clone(), pipe.nms_out[1].clone()
+    got_mask_sum = int(pipe.mask_out.sum(dtype=torch.int64).item()) if pipe.mask_out is not None else 0
+    ref = pipe.step(last, fork=False)
+    torch.cuda.synchronize()
+    cnt = ref[1].tolist()
+    replay_ok = bool(torch.equal(got_lb, pipe.lb_out) and torch.equal(got_count, ref[1])
+                     and all(torch.equal(got_det[b, :c], ref[0][b, :c]) for b, c in enumerate(cnt))
+                     and (pipe.mask_out is None or got_mask_sum == int(pipe.mask_out.sum(dtype=torch.int64).item())))
+    if not replay_ok:
+        raise RuntimeError("bench: the timed replay's outputs differ from an eager pass over the same batch")
+
     # ---- per-kernel timing with HIP events on the stream each kernel runs on (eager passes, after the timed region) ----
     n_ev = min(max(steps, 4), 40)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
@@ -413,6 +428,7 @@ def main():
                        "per_rank": [{"images": int(r["images"]), "survivors": int(r["survivors"]), "kept_checksum": (int(r["chk_hi"]) << 31) | int(r["chk_lo"])} for r in reports],
                        "mask_dtype": "uint8", "forward": "excluded", "launch": ("one hip graph per block of %d steps" % steps) if block_graph is not None else "one hip graph replay per step" if graphs is not None else "eager",
                        "streams": "letterbox forked beside NMS sort+suppress+finalize" if fork else "one", "mask_logits": args.mask_logits,
+                       "replay_equals_eager": replay_ok,
                        "step_overlap": ("letterbox stream joined once per block: step k+1's candidate filter may run beside step k's letterbox"
                                         if (block_graph is not None and args.pipeline_steps and fork and not cfg["nm"]) else "none: every step joins its streams"),
                        "sharding": f"{world} x independent batches, no collective on the hot path"},
