@@ -312,7 +312,11 @@ int lmi_scale_coords(float *det, const int32_t *count, int batch, int max_det, i
  *               (out_elems = elements out_masks holds).  The caller knows the survivor counts at that point (it
  *               sized the buffer from them): n_masks must equal slot_base[b+1] - slot_base[b].
  *   flags       LMI_MASK_LOGITS_MFMA: the coefficient x prototype product as dense fp32 MFMA tiles for every shape;
- *               LMI_MASK_UPSAMPLE_SINGLE: the one-pass upsample kernel for every shape (both: measurement)
+ *               LMI_MASK_UPSAMPLE_SINGLE: the one-pass upsample kernel for every shape (both: measurement);
+ *               LMI_MASK_PROTO_F16: `proto` holds fp16 values, the prototypes of an `fp16=True` model
+ *               (object_detectors/yolov8_lmi/model.py:68,132).  process_mask_native multiplies `protos.float()`: every
+ *               value is promoted to fp32 as it is loaded (exact), so the masks equal those of the converted tensor
+ *               without the conversion pass.  Even prototype widths only (the row kernel); LMI_ERR_BAD_ARG otherwise.
  */
 typedef struct lmi_mask_image {
   int32_t h0, w0;      /* original frame size of this image */
@@ -320,8 +324,8 @@ typedef struct lmi_mask_image {
   int32_t reserved;
   int64_t out_offset;  /* element offset of the image's first mask in out_masks */
 } lmi_mask_image;
-enum lmi_mask_flags { LMI_MASK_LOGITS_MFMA = 1, LMI_MASK_UPSAMPLE_SINGLE = 2 };
-int lmi_mask_logits_ex(const float *proto, int batch, int nm, int mh, int mw, const float *det, int max_det,
+enum lmi_mask_flags { LMI_MASK_LOGITS_MFMA = 1, LMI_MASK_UPSAMPLE_SINGLE = 2, LMI_MASK_PROTO_F16 = 4 };
+int lmi_mask_logits_ex(const void *proto, int batch, int nm, int mh, int mw, const float *det, int max_det,
                        int det_stride, const int32_t *slot_map, const int32_t *slot_base, int h0, int w0,
                        const lmi_mask_image *images_host, const lmi_mask_image *images_dev,
                        int64_t capacity_masks, void *workspace, int64_t workspace_bytes, int flags, void *stream);
@@ -330,7 +334,7 @@ int lmi_mask_upsample_ex(void *workspace, int batch, int nm, int mh, int mw, con
                          const lmi_mask_image *images_host, const lmi_mask_image *images_dev, void *out_masks,
                          int out_dtype, int64_t capacity_masks, int64_t out_elems, int32_t *overflow, int flags,
                          void *stream);
-int lmi_process_mask_ex(const float *proto, int batch, int nm, int mh, int mw, const float *det, int max_det,
+int lmi_process_mask_ex(const void *proto, int batch, int nm, int mh, int mw, const float *det, int max_det,
                         int det_stride, const int32_t *slot_map, const int32_t *slot_base, int h0, int w0,
                         const lmi_mask_image *images_host, const lmi_mask_image *images_dev, void *out_masks,
                         int out_dtype, int64_t capacity_masks, int64_t out_elems, int32_t *overflow,

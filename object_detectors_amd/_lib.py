@@ -38,7 +38,7 @@ class lmi_mask_image(C.Structure):
     _fields_ = [("h0", C.c_int32), ("w0", C.c_int32), ("n_masks", C.c_int32), ("reserved", C.c_int32), ("out_offset", C.c_int64)]
 
 
-LMI_MASK_LOGITS_MFMA, LMI_MASK_UPSAMPLE_SINGLE = 1, 2
+LMI_MASK_LOGITS_MFMA, LMI_MASK_UPSAMPLE_SINGLE, LMI_MASK_PROTO_F16 = 1, 2, 4
 
 
 class lmi_point_op(C.Structure):

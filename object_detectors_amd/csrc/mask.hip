@@ -23,6 +23,8 @@
 //                        LMI_MASK_UPSAMPLE_SINGLE selects it for every shape.
 // Every kernel takes the geometry per image (MaskBatch): a batch of differently sized originals
 // (object_detectors/yolov8_lmi/model.py:215-236 loops over them) is one launch, masks packed back to back.
+#include <hip/hip_fp16.h>
+
 #include <mutex>
 
 #include "common.h"
@@ -68,7 +70,7 @@ __device__ __forceinline__ long long mask_offset(const MaskBatch &M, const MaskG
 }
 
 struct GemmParams {
-  const float *proto;  // (batch, 32, mh, mw)
+  const void *proto;   // (batch, 32, mh, mw), fp32 or (rows kernel only) fp16
   const float *det;    // (batch, max_det, det_stride)
   const int *slot_map;
   const int *slot_base;
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256) void mask_gemm_kernel(GemmParams G) {
   if (ulo > uhi) return;
   const int npx = wh * g.mw;
   const int plane = g.mh * g.mw;
-  const float *pb = G.proto + (size_t)b * 32 * plane + (size_t)g.top * g.mw;
+  const float *pb = reinterpret_cast<const float *>(G.proto) + (size_t)b * 32 * plane + (size_t)g.top * g.mw;
 
   // A fragments: coef[row0 + (lane&31)][2s + (lane>>5)], s = 0..15
   float a[16];
@@ -227,6 +229,9 @@ __global__ __launch_bounds__(256) void mask_gemm_kernel(GemmParams G) {
 constexpr int kSurvBatch = 128;  // survivors staged per pass: 128 * (32 coef + 4 range) * 4 B = 18 KiB of LDS
 constexpr int kLogitTileW = 32, kLogitTileH = 4;
 
+// PT: float, or __half for the prototypes of an fp16 model (`fp16=True`, object_detectors/yolov8_lmi/model.py:68): every
+// value is promoted to fp32 as it is loaded, the result of `protos.float()` without that pass over the tensor.
+template <typename PT>
 __global__ __launch_bounds__(256, 4) void mask_logits_rows_kernel(GemmParams G) {
   typedef float float2v __attribute__((ext_vector_type(2)));
   __shared__ __attribute__((aligned(16))) float coef[kSurvBatch][32];
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(256, 4) void mask_logits_rows_kernel(GemmParams G) 
   const MaskGeom g = image_geom(G.M, b);
   const int wh = g.bottom - g.top, ww = g.right - g.left, mw = g.mw;
   const int plane = g.mh * mw;
-  const float *pb = G.proto + (size_t)b * 32 * plane + (size_t)g.top * mw;
+  const PT *pb = reinterpret_cast<const PT *>(G.proto) + (size_t)b * 32 * plane + (size_t)g.top * mw;
   const float scale_h = (float)wh / (float)g.h0, scale_w = (float)ww / (float)g.w0;
   const int tiles_x = (mw + kLogitTileW - 1) / kLogitTileW;
   // ragged batch: the grid spans the largest window
@@ -271,14 +276,21 @@ __global__ __launch_bounds__(256, 4) void mask_logits_rows_kernel(GemmParams G) 
     uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(reinterpret_cast<uintptr_t>(pb) & 0xffffffffu));
     uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(reinterpret_cast<uintptr_t>(pb) >> 32));
     const void *ubase = reinterpret_cast<const void *>(((uintptr_t)hi << 32) | lo);
-    const uint32_t bytes = (uint32_t)((31u * (uint32_t)plane + (uint32_t)(wh * mw)) * 4u);   // this image's window, channel 0 .. 31
+    constexpr uint32_t esz = (uint32_t)sizeof(PT);
+    const uint32_t bytes = (uint32_t)((31u * (uint32_t)plane + (uint32_t)(wh * mw)) * esz);   // this image's window, channel 0 .. 31
     auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ubase), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-    const uint32_t voff = pv ? (uint32_t)p * 4u : 0xfffffff0u;
+    const uint32_t voff = pv ? (uint32_t)p * esz : 0xfffffff0u;
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
-      auto t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, (uint32_t)k * (uint32_t)plane * 4u, 0);
-      const uint32_t t0 = t[0], t1 = t[1];   // (a bit_cast applied to a vector element reads element 0 both times)
-      bf[k] = float2v{__uint_as_float(t0), __uint_as_float(t1)};
+      if constexpr (sizeof(PT) == 4) {
+        auto t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, (uint32_t)k * (uint32_t)plane * esz, 0);
+        const uint32_t t0 = t[0], t1 = t[1];   // (a bit_cast applied to a vector element reads element 0 both times)
+        bf[k] = float2v{__uint_as_float(t0), __uint_as_float(t1)};
+      } else {   // the lane's pixel pair is one dword of two halves
+        const uint32_t t = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (uint32_t)k * (uint32_t)plane * esz, 0);
+        const __half2 h = __builtin_bit_cast(__half2, t);
+        bf[k] = float2v{__low2float(h), __high2float(h)};
+      }
     }
   }
 
@@ -809,7 +821,7 @@ int64_t lmi_mask_workspace_bytes(int64_t capacity_masks, int mh, int mw) {
   return (int64_t)(align_up((size_t)capacity_masks * mh * mw * sizeof(float), 256) + align_up((size_t)capacity_masks * sizeof(int4), 256));
 }
 
-int lmi_mask_logits_ex(const float *proto, int batch, int nm, int mh, int mw, const float *det, int max_det, int det_stride,
+int lmi_mask_logits_ex(const void *proto, int batch, int nm, int mh, int mw, const float *det, int max_det, int det_stride,
                        const int32_t *slot_map, const int32_t *slot_base, int h0, int w0, const lmi_mask_image *images_host,
                        const lmi_mask_image *images_dev, int64_t capacity_masks, void *workspace, int64_t workspace_bytes, int flags,
                        void *stream) {
@@ -826,11 +838,15 @@ int lmi_mask_logits_ex(const float *proto, int batch, int nm, int mh, int mw, co
   G.table = reinterpret_cast<int4 *>(reinterpret_cast<char *>(workspace) + align_up((size_t)capacity_masks * mh * mw * sizeof(float), 256));
   const int npx = C.max_wh * mw;   // the largest window of the batch; tiles beyond an image's own window leave at once
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (!(flags & LMI_MASK_LOGITS_MFMA) && (mw % 2) == 0 && lmi_is_aligned(proto, 8)) {
+  const bool half = (flags & LMI_MASK_PROTO_F16) != 0;
+  if (!(flags & LMI_MASK_LOGITS_MFMA) && (mw % 2) == 0 && lmi_is_aligned(proto, half ? 4 : 8)) {
     const int tiles = ((mw + kLogitTileW - 1) / kLogitTileW) * ((C.max_wh + kLogitTileH - 1) / kLogitTileH);
-    hipLaunchKernelGGL(mask_logits_rows_kernel, dim3((tiles + 3) / 4, batch), dim3(256), 0, s, G);
+    if (half) hipLaunchKernelGGL(mask_logits_rows_kernel<__half>, dim3((tiles + 3) / 4, batch), dim3(256), 0, s, G);
+    else hipLaunchKernelGGL(mask_logits_rows_kernel<float>, dim3((tiles + 3) / 4, batch), dim3(256), 0, s, G);
     return lmi_check_launch("mask_logits_rows_kernel");
   }
+  LMI_REQUIRE(!half, LMI_ERR_BAD_ARG, "lmi_mask_logits: fp16 prototypes are served by the row kernel only (even width, 4-byte aligned, "
+              "no LMI_MASK_LOGITS_MFMA): convert them to fp32 for this shape");
   hipLaunchKernelGGL(mask_slot_table_kernel, dim3((unsigned)((capacity_masks + 255) / 256)), dim3(256), 0, s, G);
   // dense MFMA tiles: 4 adjacent pixels per lane when rows are whole 16-byte vectors, else one pixel per lane
   const bool vec4 = (mw % 4) == 0 && lmi_is_aligned(proto, 16);
@@ -914,7 +930,7 @@ int lmi_mask_upsample_ex(void *workspace, int batch, int nm, int mh, int mw, con
   return lmi_check_launch("mask_upsample_kernel");
 }
 
-int lmi_process_mask_ex(const float *proto, int batch, int nm, int mh, int mw, const float *det, int max_det, int det_stride,
+int lmi_process_mask_ex(const void *proto, int batch, int nm, int mh, int mw, const float *det, int max_det, int det_stride,
                         const int32_t *slot_map, const int32_t *slot_base, int h0, int w0, const lmi_mask_image *images_host,
                         const lmi_mask_image *images_dev, void *out_masks, int out_dtype, int64_t capacity_masks, int64_t out_elems,
                         int32_t *overflow, void *workspace, int64_t workspace_bytes, int flags, void *stream) {

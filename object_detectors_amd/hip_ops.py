@@ -19,17 +19,23 @@ _L = _lib.load()
 
 
 class _WorkspaceCache:
-    """One growing byte buffer per (device, stream, tag): the library itself never allocates."""
+    """One growing byte buffer per (device, stream, tag): the library itself never allocates.  At most `limit` buffers
+    are held, the least recently used one is dropped first (a process that keeps creating streams would otherwise pin
+    one workspace per stream handle it ever used; a dropped buffer goes back to torch's allocator, which orders its
+    reuse after the work enqueued on the stream it was allocated on)."""
 
-    def __init__(self):
+    def __init__(self, limit: int = 32):
         self._buf = {}
+        self._limit = limit
 
     def get(self, device: torch.device, tag: str, nbytes: int) -> torch.Tensor:
         key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
-        t = self._buf.get(key)
+        t = self._buf.pop(key, None)
         if t is None or t.numel() < nbytes:
             t = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=device)
-            self._buf[key] = t
+        self._buf[key] = t                  # most recently used last (dicts keep insertion order)
+        while len(self._buf) > self._limit:
+            self._buf.pop(next(iter(self._buf)))
         return t
 
 
@@ -372,9 +378,13 @@ def _check_window(mh: int, mw: int, h0: int, w0: int) -> None:
                            f"output (H: {h0}, W: {w0})")
 
 
-def _mask_inputs(proto, det, slot_map, slot_base):
+def _mask_inputs(proto, det, slot_map, slot_base, logits="rows"):
+    """Validated inputs -> (prototypes, flag).  The prototypes of an fp16 model (`fp16=True`) are read as they are
+    (LMI_MASK_PROTO_F16: promoted to fp32 in the kernel = `protos.float()` without that pass) whenever the row kernel
+    serves the shape; any other dtype is converted first."""
     _need_cuda(proto, "proto")
-    if proto.dtype != torch.float32:
+    half = proto.dtype == torch.float16 and logits == "rows" and proto.ndim == 4 and proto.shape[-1] % 2 == 0
+    if proto.dtype != torch.float32 and not half:
         proto = proto.float()
     if not proto.is_contiguous():
         proto = proto.contiguous()
@@ -384,7 +394,7 @@ def _mask_inputs(proto, det, slot_map, slot_base):
             raise ValueError(f"process_mask: {name} must be a contiguous {dt} tensor on the prototypes' device")
     if det.ndim != 3 or det.shape[0] != proto.shape[0] or slot_base.numel() != proto.shape[0] + 1:
         raise ValueError("process_mask: det must be (B,max_det,6+nm) and slot_base (B+1,)")
-    return proto
+    return proto, (_lib.LMI_MASK_PROTO_F16 if half else 0)
 
 
 def process_mask(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.Tensor, slot_base: torch.Tensor,
@@ -399,7 +409,7 @@ def process_mask(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.Tensor,
     before_upsample: optional callable run between the two halves (e.g. joining another stream: nothing should run
     beside the upsample's zero fill, see profiles/r01/write_ceiling.md).
     logits='mfma' / upsample='single' select the dense MFMA product / the one-pass upsample kernel (measurement)."""
-    proto = _mask_inputs(proto, det, slot_map, slot_base)
+    proto, pflag = _mask_inputs(proto, det, slot_map, slot_base, logits)
     b, nm, mh, mw = proto.shape
     _, max_det, stride = det.shape
     h0, w0 = int(orig_hw[0]), int(orig_hw[1])
@@ -413,7 +423,7 @@ def process_mask(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.Tensor,
     overflow = torch.empty((1,), dtype=torch.int32, device=proto.device)
     nbytes = int(_L.lmi_mask_workspace_bytes(capacity, mh, mw))
     ws = _ws.get(proto.device, "mask", nbytes)
-    flags, st = _mask_flags(logits, upsample), _stream(proto.device)
+    flags, st = _mask_flags(logits, upsample) | pflag, _stream(proto.device)
     if split_events is None and before_upsample is None:
         check(_L.lmi_process_mask_ex(proto.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
                                      slot_base.data_ptr(), h0, w0, None, None, out.data_ptr(), ldt, capacity, 0, overflow.data_ptr(),
@@ -441,7 +451,7 @@ def process_mask_ragged(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.
     image b as read from slot_base (the caller synchronised to size its outputs anyway).  The masks are packed into
     one flat buffer, every image's block starting on a 16-element boundary; returns the per-image views
     [(counts[b], H0_b, W0_b)], empty images included."""
-    proto = _mask_inputs(proto, det, slot_map, slot_base)
+    proto, pflag = _mask_inputs(proto, det, slot_map, slot_base, logits)
     b, nm, mh, mw = proto.shape
     _, max_det, stride = det.shape
     if len(sizes) != b or len(counts) != b:
@@ -465,7 +475,7 @@ def process_mask_ragged(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.
     st = _stream(dev)
     check(_L.lmi_process_mask_ex(proto.data_ptr(), b, nm, mh, mw, det.data_ptr(), max_det, stride, slot_map.data_ptr(),
                                  slot_base.data_ptr(), 0, 0, C.addressof(desc), ddev.data_ptr(), flat.data_ptr(), ldt, total, flat.numel(),
-                                 None, ws.data_ptr(), ws.numel(), _mask_flags(logits, upsample), st))
+                                 None, ws.data_ptr(), ws.numel(), _mask_flags(logits, upsample) | pflag, st))
     ddev.record_stream(torch.cuda.current_stream(dev))
     return views
 

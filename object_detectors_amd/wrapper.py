@@ -414,9 +414,8 @@ class Yolov8PoseCore(Yolov8Core):
         det, count, _ = ops.nms_v8(preds, float(conf2), float(iou), agnostic=bool(agnostic), max_det=int(max_det), nc=nc)
         fin = ops.finalize_detections(det, count, nc, model_hw, ohw, thres, with_slots=False)
         ops.scale_coords(det, count, nkpt, ndim, model_hw, ohw)
-        count_h = count.cpu().numpy()
-        keep_h = fin["keep"].cpu().numpy().astype(bool)
-        det_h = det.cpu().numpy()
+        count_h, keep_h, det_h = self._to_host([count, fin["keep"], det])   # pinned, asynchronous, ONE synchronisation
+        keep_h = keep_h.astype(bool)
         results = collections.defaultdict(list)
         names = self.model.names
         for i in range(B):
@@ -497,11 +496,9 @@ class Yolov8ObbCore(Yolov8Core):
         ohw = shapes[0] if all(s == shapes[0] for s in shapes) else torch.tensor(shapes, dtype=torch.int32, device=self.device)
         det, count, _ = ops.nms_v8(preds, float(conf2), float(iou), agnostic=bool(agnostic), max_det=int(max_det), nc=nc, rotated=True)
         fin = ops.finalize_obb(det, count, nc, model_hw, ohw, thres)
-        count_h = count.cpu().numpy()
-        keep_h = fin["keep"].cpu().numpy().astype(bool)
-        det_h = det[:, :, :6].cpu().numpy()
         corners = fin["corners"]
-        corners_h = corners.cpu().numpy()
+        count_h, keep_h, det_h, corners_h = self._to_host([count, fin["keep"], det[:, :, :6], corners])   # ONE synchronisation
+        keep_h = keep_h.astype(bool)
         results = collections.defaultdict(list)
         names = self.model.names
         for i in range(B):

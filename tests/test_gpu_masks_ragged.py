@@ -113,3 +113,42 @@ def test_interpolation_is_bit_exact_against_torch_cpu(ops, h0, w0, mh, mw):
         for upsample in ("split", "single"):
             got, _ = ops.process_mask(dev(proto), dev(det), dev(sm), dev(sb), (h0, w0), n, dtype, upsample=upsample)
             assert np.array_equal(got.cpu().numpy() != 0, ref), (dtype, upsample, int((got.cpu().numpy().astype(bool) != ref).sum()))
+
+
+def test_fp16_prototypes_equal_the_converted_tensor(ops):
+    """`fp16=True` models (object_detectors/yolov8_lmi/model.py:68,132) hand fp16 prototypes to process_mask_native,
+    which multiplies `protos.float()`: the kernel reads the halves as they are (LMI_MASK_PROTO_F16) and must give the
+    masks of the converted tensor bit for bit -- uniform and ragged originals, and against the oracle on the rounded
+    values; an odd prototype width (no row kernel) is converted on the way in."""
+    from object_detectors_amd import _lib
+    rng = np.random.default_rng(63)
+    sizes = [(1080, 1920), (480, 640), (375, 500), (720, 1280)]
+    counts = [6, 3, 4, 5]
+    B, mh, mw, max_det = len(sizes), 160, 160, 8
+    proto16 = dev(synth.proto(rng, B, 32, mh, mw)).half()
+    proto32 = proto16.float()
+    det, sm, sb = scene(rng, sizes, counts, max_det)
+    a = ops.process_mask_ragged(proto16, dev(det), dev(sm), dev(sb), sizes, counts, torch.uint8)
+    b = ops.process_mask_ragged(proto32, dev(det), dev(sm), dev(sb), sizes, counts, torch.uint8)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y) and int(x.sum()) > 0, i
+        ref = OM.process_mask_native(proto32[i].cpu().numpy(), det[i, :counts[i], 6:], det[i, :counts[i], :4], sizes[i])
+        assert OM.mask_iou(x.cpu().numpy(), ref) >= 0.999, i
+    # uniform originals, the whole batch at the first size
+    sm_u = np.full(B * max_det, -1, np.int32)
+    sm_u[:sb[-1]] = np.concatenate([i * max_det + np.arange(n) for i, n in enumerate(counts)])
+    u16, _ = ops.process_mask(proto16, dev(det), dev(sm_u), dev(sb), sizes[0], int(sb[-1]), torch.uint8)
+    u32, _ = ops.process_mask(proto32, dev(det), dev(sm_u), dev(sb), sizes[0], int(sb[-1]), torch.uint8)
+    assert torch.equal(u16, u32)
+    # odd width: hip_ops converts (the MFMA tiles read fp32 only) ...
+    p_odd = dev(synth.proto(rng, 1, 32, 41, 41)).half()
+    o16, _ = ops.process_mask(p_odd, dev(det[:1]), dev(sm_u[:max_det]), dev(np.array([0, counts[0]], np.int32)), (270, 480), counts[0], torch.uint8)
+    o32, _ = ops.process_mask(p_odd.float(), dev(det[:1]), dev(sm_u[:max_det]), dev(np.array([0, counts[0]], np.int32)), (270, 480), counts[0], torch.uint8)
+    assert torch.equal(o16, o32)
+    # ... and the C ABI refuses the flag where the row kernel cannot serve it
+    L = _lib.load()
+    ws = torch.empty((int(L.lmi_mask_workspace_bytes(8, 41, 41)),), dtype=torch.uint8, device="cuda")
+    d, m, s = dev(det[:1]), dev(sm_u[:max_det]), dev(np.array([0, counts[0]], np.int32))
+    rc = L.lmi_mask_logits_ex(p_odd.data_ptr(), 1, 32, 41, 41, d.data_ptr(), max_det, 38, m.data_ptr(), s.data_ptr(), 270, 480, None, None,
+                              8, ws.data_ptr(), ws.numel(), _lib.LMI_MASK_PROTO_F16, None)
+    assert rc == -1 and b"fp16 prototypes" in L.lmi_last_error()
