@@ -44,6 +44,8 @@ enum lmi_dtype { LMI_F32 = 0, LMI_F16 = 1, LMI_U8 = 2 };
 
 /* resampler of the letterbox entry: the fixed-point cv2.INTER_LINEAR (default) */
 enum lmi_resize_mode { LMI_RESIZE_CV2_LINEAR = 0, LMI_RESIZE_TORCH_BILINEAR = 1, LMI_RESIZE_TORCH_BILINEAR_1T = 2 };
+/* OR-ed into `mode`: the source frames are single grey planes (uint8 HW, one byte per pixel) */
+#define LMI_SRC_GRAY 0x100
 
 #define LMI_MAX_DET_CAP 1024   /* largest max_det lmi_nms_v8 accepts */
 #define LMI_MAX_MASK_DIM 32    /* number of prototype channels (nm) the mask kernels are built for */
@@ -80,9 +82,9 @@ int lmi_letterbox_geometry(int h, int w, int dst_h, int dst_w, int stretch, int3
 
 /* one source frame of a ragged batch; the array lives in device memory */
 typedef struct lmi_frame {
-  uint64_t src;        /* [device] uint8 HWC, 3 channels, 16-byte aligned */
+  uint64_t src;        /* [device] uint8 HWC, 3 channels (one with LMI_SRC_GRAY), 16-byte aligned */
   int32_t h, w;        /* source size */
-  int32_t row_stride;  /* bytes between source rows, >= 3*w */
+  int32_t row_stride;  /* bytes between source rows, >= 3*w (>= w with LMI_SRC_GRAY) */
   int32_t new_w, new_h;/* resized content size (lmi_letterbox_geometry) */
   int32_t pad_l, pad_t;/* where the content starts in the destination */
   int32_t reserved;
@@ -116,6 +118,11 @@ typedef struct lmi_frame {
  * workspace: as for the cv2 mode -- the tables then hold aten's indices and fp32 weights and the same LDS-staged kernel
  * runs (as fast as the cv2 mode); NULL or too small a workspace selects a table-free kernel that reads its taps straight
  * from global memory (2-3 x slower, same result).
+ * mode | LMI_SRC_GRAY (either resampler, both entries): every frame is ONE grey plane.  The callers turn such an image
+ * into three equal channels before they resize it -- cv2.cvtColor(im0, COLOR_GRAY2BGR),
+ * object_detectors/yolov8_lmi/run_model.py:77-78 and ultralytics_lmi/yolo/run_model.py:78-79; preprocess itself
+ * expands a 1-channel input, model.py:123-126 -- and both resamplers treat channels independently, so the plane is
+ * resampled once and the value written to the three output planes: the same tensor, a third of the source bytes.
  */
 int64_t lmi_letterbox_workspace_bytes(int table_sets, int dst_h, int dst_w);
 int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, int batch,

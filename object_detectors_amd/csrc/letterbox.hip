@@ -186,7 +186,11 @@ struct OutTraits<__half> {
 // TORCH: the tables hold aten's source indices and fp32 weights, the arithmetic is aten's CPU bilinear on the fp32 cast
 // with a truncating cast back (the reference helpers' resize_image); staging, tiles and stores are
 // the same.
-template <typename OutT, int TW, int TH, int KF, bool TORCH>
+// CH: bytes per source pixel, 3 (HWC colour) or 1 (a grey plane: the callers replicate it to three channels BEFORE they
+// resize -- cv2.cvtColor(GRAY2BGR), object_detectors/yolov8_lmi/run_model.py:77-78; `expand(-1,-1,3)`,
+// model.py:125-126 -- and the resize treats channels independently, so resampling the plane once and writing the value
+// to the three output planes is the same tensor for a third of the source bytes).
+template <typename OutT, int TW, int TH, int KF, bool TORCH, int CH>
 __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
   constexpr int NT = (TW / 4) * TH;
   extern __shared__ __attribute__((aligned(16))) unsigned char rows[];
@@ -248,14 +252,14 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
   // ---- stage source rows -------------------------------------------------------------------------
   const int sx_min = xt[cx0].x;
   const int sx_max = min(xt[cx1 - 1].x + 1, w - 1);
-  const int span_b0 = sx_min * 3;                              // first needed byte within a row
-  const int span_bytes = (sx_max - sx_min + 1) * 3;
+  const int span_b0 = sx_min * CH;                             // first needed byte within a row
+  const int span_bytes = (sx_max - sx_min + 1) * CH;
   const int nchunk = (span_bytes + 15 + 15) >> 4;              // covers any 0..15 byte alignment shift
   {
     // Range-checked loads are dropped whole when they cross num_records, so the range is the frame
     // rounded up to the 16-byte chunk size.  The base is 16-byte aligned, hence the rounded end is too and
     // the last chunk stays inside the page that holds the frame's last byte: no access can fault.
-    const uint32_t frame_bytes = (uint32_t)(((long long)(h - 1) * stride + 3LL * w + 15) & ~15LL);
+    const uint32_t frame_bytes = (uint32_t)(((long long)(h - 1) * stride + (long long)CH * w + 15) & ~15LL);
     uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(reinterpret_cast<uintptr_t>(src) & 0xffffffffu));
     uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(reinterpret_cast<uintptr_t>(src) >> 32));
     const void *ubase = reinterpret_cast<const void *>(((uintptr_t)hi << 32) | lo);
@@ -335,30 +339,39 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
         // Both second weights are 0 (a0 = b0 = 2048): the fixed-point sum is the left upper tap itself,
         // ((2048 * ((s * 2048) >> 4)) >> 16 + 2) >> 2 = s.  Every pixel of an exact odd reduction (1080p -> 640x360:
         // fx = 3 dx + 1) or of a frame already at model size takes this branch: one tap, no arithmetic.
-        const int p = base0 + s * 3;
+        const int p = base0 + s * CH;
         const int wi = p >> 2;
         const uint32_t t = __builtin_amdgcn_alignbyte(rw[wi + 1], rw[wi], (uint32_t)(p & 3));
+        if constexpr (CH == 1) {
+          out[0][k] = out[1][k] = out[2][k] = TR::make((int)(t & 0xffu));
+        } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) out[c][k] = TR::make((int)((t >> (8 * c)) & 0xffu));
+          for (int c = 0; c < 3; ++c) out[c][k] = TR::make((int)((t >> (8 * c)) & 0xffu));
+        }
         continue;
       }
       uint32_t px[2][2];  // [row][0: bytes p..p+3, 1: bytes p+4..p+7]
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr) {
-        const int p = (rr == 0 ? base0 : base1) + s * 3;
+        const int p = (rr == 0 ? base0 : base1) + s * CH;
         const int wi = p >> 2;
         const uint32_t sh = (uint32_t)(p & 3);
-        const uint32_t d0 = rw[wi], d1 = rw[wi + 1], d2 = rw[wi + 2];
-        px[rr][0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
-        px[rr][1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        if constexpr (CH == 1) {   // bytes p, p + 1 only
+          px[rr][0] = __builtin_amdgcn_alignbyte(rw[wi + 1], rw[wi], sh);
+          px[rr][1] = 0u;
+        } else {
+          const uint32_t d0 = rw[wi], d1 = rw[wi + 1], d2 = rw[wi + 2];
+          px[rr][0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+          px[rr][1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        }
       }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        // pixel s: byte c ; pixel s+1: byte 3+c
+      for (int c = 0; c < CH; ++c) {
+        // pixel s: byte c ; pixel s+1: byte CH+c
         const int s00 = (int)((px[0][0] >> (8 * c)) & 0xffu);
         const int s10 = (int)((px[1][0] >> (8 * c)) & 0xffu);
-        const int s01 = (c == 0) ? (int)(px[0][0] >> 24) : (int)((px[0][1] >> (8 * (c - 1))) & 0xffu);
-        const int s11 = (c == 0) ? (int)(px[1][0] >> 24) : (int)((px[1][1] >> (8 * (c - 1))) & 0xffu);
+        const int s01 = CH == 1 ? (int)((px[0][0] >> 8) & 0xffu) : (c == 0) ? (int)(px[0][0] >> 24) : (int)((px[0][1] >> (8 * (c - 1))) & 0xffu);
+        const int s11 = CH == 1 ? (int)((px[1][0] >> 8) & 0xffu) : (c == 0) ? (int)(px[1][0] >> 24) : (int)((px[1][1] >> (8 * (c - 1))) & 0xffu);
         if constexpr (TORCH) {
           // aten: at the right border both horizontal taps are the last pixel; a lower row that was not staged has
           // weight 0 and whatever finite bytes the LDS holds
@@ -374,13 +387,14 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
             v = fmaf(t0, ly0, t1 * ly1);
           }
           out[c][k] = TR::make((int)v);   // `.to(uint8)`: truncation (the value lies in [0, 255.00002])
-          continue;
+        } else {
+          const int h0 = s00 * a0 + s01 * a1;
+          const int h1 = s10 * a0 + s11 * a1;
+          const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+          out[c][k] = TR::make(v);
         }
-        const int h0 = s00 * a0 + s01 * a1;
-        const int h1 = s10 * a0 + s11 * a1;
-        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        out[c][k] = TR::make(v);
       }
+      if constexpr (CH == 1) out[1][k] = out[2][k] = out[0][k];
     }
   }
 #pragma unroll
@@ -448,7 +462,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restri
 // fma(scale, d + 0.5, -0.5) clamped at 0; then the per-pixel 4-weight kernel aten runs when out_h + out_w <= 128,
 // else its separable kernel (horizontal pairs, then vertical, each fma(a, wa, b*wb)).
 // One lane = 4 output pixels x 3 channels; taps are read straight from L2/HBM (12 bytes per tap pair).
-template <typename OutT>
+template <typename OutT, int CH>
 __global__ __launch_bounds__(256) void letterbox_torch_kernel(LbParams P) {
   using TR = OutTraits<OutT>;
   using reg_t = typename TR::reg;
@@ -484,9 +498,9 @@ __global__ __launch_bounds__(256) void letterbox_torch_kernel(LbParams P) {
     float lx0, lx1;
     aten_linear_src(scale_w, dx, w, ix0, ix1, lx0, lx1);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float i00 = (float)r0[ix0 * 3 + c], i01 = (float)r0[ix1 * 3 + c];
-      const float i10 = (float)r1[ix0 * 3 + c], i11 = (float)r1[ix1 * 3 + c];
+    for (int c = 0; c < CH; ++c) {
+      const float i00 = (float)r0[ix0 * CH + c], i01 = (float)r0[ix1 * CH + c];
+      const float i10 = (float)r1[ix0 * CH + c], i11 = (float)r1[ix1 * CH + c];
       float v;
       if (weights4) {
         const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
@@ -497,6 +511,7 @@ __global__ __launch_bounds__(256) void letterbox_torch_kernel(LbParams P) {
       }
       out[c][k] = TR::make((int)v);   // `.to(uint8)`: truncation (the value lies in [0, 255.00002])
     }
+    if constexpr (CH == 1) out[1][k] = out[2][k] = out[0][k];
   }
   const long long plane = (long long)P.dst_h * P.dst_w;
   OutT *dst = reinterpret_cast<OutT *>(P.dst) + (long long)b * 3 * plane;
@@ -515,18 +530,19 @@ __global__ __launch_bounds__(256) void letterbox_torch_kernel(LbParams P) {
 }
 
 template <typename OutT>
-int launch_letterbox_torch(const LbParams &P, int batch, hipStream_t stream) {
+int launch_letterbox_torch(const LbParams &P, int batch, int ch, hipStream_t stream) {
   dim3 grid((P.dst_w + 255) / 256, (P.dst_h + 3) / 4, batch);
-  hipLaunchKernelGGL(letterbox_torch_kernel<OutT>, grid, dim3(256), 0, stream, P);
+  if (ch == 1) hipLaunchKernelGGL((letterbox_torch_kernel<OutT, 1>), grid, dim3(256), 0, stream, P);
+  else hipLaunchKernelGGL((letterbox_torch_kernel<OutT, 3>), grid, dim3(256), 0, stream, P);
   return lmi_check_launch("letterbox_torch_kernel");
 }
 
-int lds_pitch_for(int w, int new_w, int tw) {
+int lds_pitch_for(int w, int new_w, int tw, int ch) {
   // widest source span (pixels) a tile of `tw` output columns can touch, +1 neighbour, +alignment slack
   double scale = (double)w / (double)new_w;
   long span_px = (long)(scale * tw) + 3;
   if (span_px > w) span_px = w;
-  long bytes = span_px * 3 + 15 + 15 + 12;  // alignment shift + chunk rounding + 3-dword tap window
+  long bytes = span_px * ch + 15 + 15 + 12;  // alignment shift + chunk rounding + 3-dword tap window
   return (int)((bytes + 15) & ~15L);
 }
 
@@ -547,9 +563,9 @@ TabLayout tab_layout(int sets, int dst_h, int dst_w) {
   return L;
 }
 
-template <typename OutT, bool TORCH>
-int launch_letterbox(const LbParams &P0, int batch, int sets, int max_pitch128, int max_pitch32, void *workspace,
-                     int64_t workspace_bytes, hipStream_t stream) {
+template <typename OutT, bool TORCH, int CH>
+int launch_letterbox_ch(const LbParams &P0, int batch, int sets, int max_pitch128, int max_pitch32, void *workspace,
+                        int64_t workspace_bytes, hipStream_t stream) {
   LbParams P = P0;
   const TabLayout L = tab_layout(sets, P.dst_h, P.dst_w);
   LMI_REQUIRE(workspace != nullptr && lmi_is_aligned(workspace, 256), LMI_ERR_ALIGNMENT, "lmi_letterbox_u8: workspace must be 256-byte aligned");
@@ -570,16 +586,16 @@ int launch_letterbox(const LbParams &P0, int batch, int sets, int max_pitch128, 
     P.tiles_y = (P.dst_h + kTH - 1) / kTH;
     dim3 grid(P.tiles_x * P.tiles_y, batch);
     // chunks per lane of a staged row: pitch / 16 bytes over the 16 lanes that share the row
-    if (P.pitch > 8 * 256) hipLaunchKernelGGL((letterbox_kernel<OutT, 128, kTH, 12, TORCH>), grid, dim3(32 * kTH), lds_bytes_for(P.pitch), stream, P);
-    else if (P.pitch > 4 * 256) hipLaunchKernelGGL((letterbox_kernel<OutT, 128, kTH, 8, TORCH>), grid, dim3(32 * kTH), lds_bytes_for(P.pitch), stream, P);
-    else hipLaunchKernelGGL((letterbox_kernel<OutT, 128, kTH, 4, TORCH>), grid, dim3(32 * kTH), lds_bytes_for(P.pitch), stream, P);
+    if (P.pitch > 8 * 256) hipLaunchKernelGGL((letterbox_kernel<OutT, 128, kTH, 12, TORCH, CH>), grid, dim3(32 * kTH), lds_bytes_for(P.pitch), stream, P);
+    else if (P.pitch > 4 * 256) hipLaunchKernelGGL((letterbox_kernel<OutT, 128, kTH, 8, TORCH, CH>), grid, dim3(32 * kTH), lds_bytes_for(P.pitch), stream, P);
+    else hipLaunchKernelGGL((letterbox_kernel<OutT, 128, kTH, 4, TORCH, CH>), grid, dim3(32 * kTH), lds_bytes_for(P.pitch), stream, P);
   } else if (lds_bytes_for(max_pitch32) <= 2 * kMaxLds) {
     P.pitch = max_pitch32;
     P.tiles_x = (P.dst_w + 31) / 32;
     P.tiles_y = (P.dst_h + kTH - 1) / kTH;
     dim3 grid(P.tiles_x * P.tiles_y, batch);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(letterbox_kernel<OutT, 32, kTH, 4, TORCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)kMaxLds);
-    hipLaunchKernelGGL((letterbox_kernel<OutT, 32, kTH, 4, TORCH>), grid, dim3(8 * kTH), lds_bytes_for(P.pitch), stream, P);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(letterbox_kernel<OutT, 32, kTH, 4, TORCH, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)kMaxLds);
+    hipLaunchKernelGGL((letterbox_kernel<OutT, 32, kTH, 4, TORCH, CH>), grid, dim3(8 * kTH), lds_bytes_for(P.pitch), stream, P);
   } else {
     lmi_set_error("lmi_letterbox_u8: down-scale factor too large for the LDS row tiles");
     return LMI_ERR_LIMIT;
@@ -587,7 +603,16 @@ int launch_letterbox(const LbParams &P0, int batch, int sets, int max_pitch128, 
   return lmi_check_launch("letterbox_kernel");
 }
 
-int check_common(const void *dst, int dst_h, int dst_w, int dst_dtype, int pad_value, int mode, int batch) {
+template <typename OutT, bool TORCH>
+int launch_letterbox(const LbParams &P, int batch, int sets, int ch, int max_pitch128, int max_pitch32, void *workspace,
+                     int64_t workspace_bytes, hipStream_t stream) {
+  return ch == 1 ? launch_letterbox_ch<OutT, TORCH, 1>(P, batch, sets, max_pitch128, max_pitch32, workspace, workspace_bytes, stream)
+                 : launch_letterbox_ch<OutT, TORCH, 3>(P, batch, sets, max_pitch128, max_pitch32, workspace, workspace_bytes, stream);
+}
+
+int check_common(const void *dst, int dst_h, int dst_w, int dst_dtype, int pad_value, int &mode, int batch, int &ch) {
+  ch = (mode & LMI_SRC_GRAY) ? 1 : 3;   // the resampler is the low byte of `mode`
+  mode &= ~LMI_SRC_GRAY;
   LMI_REQUIRE(dst != nullptr, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: dst is NULL");
   LMI_REQUIRE(batch > 0 && batch <= 65535, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: batch %d out of range 1..65535", batch);
   LMI_REQUIRE(dst_h > 0 && dst_w > 0, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: bad destination size %dx%d", dst_h, dst_w);
@@ -599,11 +624,11 @@ int check_common(const void *dst, int dst_h, int dst_w, int dst_dtype, int pad_v
 }
 
 int check_frame(const void *src, int h, int w, long long stride, int new_w, int new_h, int pad_l, int pad_t, int dst_h, int dst_w, int i,
-                bool may_crop = false) {
+                int ch, bool may_crop = false) {
   LMI_REQUIRE(src != nullptr, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frame %d: src is NULL", i);
   LMI_REQUIRE(lmi_is_aligned(src, 16), LMI_ERR_ALIGNMENT, "lmi_letterbox_u8: frame %d: src must be 16-byte aligned", i);
-  LMI_REQUIRE(h > 0 && w > 0 && stride >= 3LL * w, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frame %d: bad size/stride (%d,%d,%lld)", i, h, w, stride);
-  LMI_REQUIRE((long long)(h - 1) * stride + 3LL * w < (1LL << 32) - 16, LMI_ERR_LIMIT, "lmi_letterbox_u8: frame %d larger than 4 GiB", i);
+  LMI_REQUIRE(h > 0 && w > 0 && stride >= (long long)ch * w, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frame %d: bad size/stride (%d,%d,%lld)", i, h, w, stride);
+  LMI_REQUIRE((long long)(h - 1) * stride + (long long)ch * w < (1LL << 32) - 16, LMI_ERR_LIMIT, "lmi_letterbox_u8: frame %d larger than 4 GiB", i);
   // the torch flavour may place the content partly outside the destination (fit_im_to_size crops, centred)
   LMI_REQUIRE(new_w > 0 && new_h > 0 && (may_crop || (pad_l >= 0 && pad_t >= 0 && pad_l + new_w <= dst_w && pad_t + new_h <= dst_h)),
               LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frame %d: content %dx%d at (%d,%d) does not fit %dx%d", i, new_w, new_h, pad_l, pad_t, dst_w, dst_h);
@@ -622,16 +647,17 @@ int64_t lmi_letterbox_workspace_bytes(int table_sets, int dst_h, int dst_w) {
 int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, int batch, void *dst, int dst_h,
                      int dst_w, int dst_dtype, int pad_value, int swap_rb, int mode, void *workspace,
                      int64_t workspace_bytes, void *stream) {
-  int rc = check_common(dst, dst_h, dst_w, dst_dtype, pad_value, mode, batch);
+  int ch = 3;
+  int rc = check_common(dst, dst_h, dst_w, dst_dtype, pad_value, mode, batch, ch);
   if (rc) return rc;
   LMI_REQUIRE(frames_host != nullptr && frames_dev != nullptr, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frames is NULL");
   int p128 = 0, p32 = 0;
   for (int i = 0; i < batch; ++i) {
     const lmi_frame &f = frames_host[i];
     rc = check_frame(reinterpret_cast<const void *>(f.src), f.h, f.w, f.row_stride, f.new_w, f.new_h, f.pad_l, f.pad_t, dst_h, dst_w, i,
-                     mode != LMI_RESIZE_CV2_LINEAR);
+                     ch, mode != LMI_RESIZE_CV2_LINEAR);
     if (rc) return rc;
-    int a = lds_pitch_for(f.w, f.new_w, 128), b = lds_pitch_for(f.w, f.new_w, 32);
+    int a = lds_pitch_for(f.w, f.new_w, 128, ch), b = lds_pitch_for(f.w, f.new_w, 32, ch);
     if (a > p128) p128 = a;
     if (b > p32) p32 = b;
   }
@@ -644,18 +670,19 @@ int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, 
     // with a workspace for the tables: the LDS-staged kernel (249 -> ~100 us per 64 x 1080p); without one, the
     // table-free kernel that reads its taps straight from global memory (the entry's contract before r02)
     if (workspace == nullptr || workspace_bytes < lmi_letterbox_workspace_bytes(batch, dst_h, dst_w))
-      return dst_dtype == LMI_F32 ? launch_letterbox_torch<float>(P, batch, s) : launch_letterbox_torch<__half>(P, batch, s);
-    return dst_dtype == LMI_F32 ? launch_letterbox<float, true>(P, batch, batch, p128, p32, workspace, workspace_bytes, s)
-                                : launch_letterbox<__half, true>(P, batch, batch, p128, p32, workspace, workspace_bytes, s);
+      return dst_dtype == LMI_F32 ? launch_letterbox_torch<float>(P, batch, ch, s) : launch_letterbox_torch<__half>(P, batch, ch, s);
+    return dst_dtype == LMI_F32 ? launch_letterbox<float, true>(P, batch, batch, ch, p128, p32, workspace, workspace_bytes, s)
+                                : launch_letterbox<__half, true>(P, batch, batch, ch, p128, p32, workspace, workspace_bytes, s);
   }
-  return dst_dtype == LMI_F32 ? launch_letterbox<float, false>(P, batch, batch, p128, p32, workspace, workspace_bytes, s)
-                              : launch_letterbox<__half, false>(P, batch, batch, p128, p32, workspace, workspace_bytes, s);
+  return dst_dtype == LMI_F32 ? launch_letterbox<float, false>(P, batch, batch, ch, p128, p32, workspace, workspace_bytes, s)
+                              : launch_letterbox<__half, false>(P, batch, batch, ch, p128, p32, workspace, workspace_bytes, s);
 }
 
 int lmi_letterbox_u8_uniform(const void *src, int batch, int h, int w, int64_t row_stride, int64_t image_stride,
                              void *dst, int dst_h, int dst_w, int dst_dtype, int pad_value, int swap_rb, int stretch,
                              int mode, void *workspace, int64_t workspace_bytes, void *stream) {
-  int rc = check_common(dst, dst_h, dst_w, dst_dtype, pad_value, mode, batch);
+  int ch = 3;
+  int rc = check_common(dst, dst_h, dst_w, dst_dtype, pad_value, mode, batch, ch);
   if (rc) return rc;
   // this form derives the geometry itself, by the cv2 / ultralytics rules (round(), centred pad); the reference
   // helpers behind the torch flavours size and pad differently (int() truncation, pipeline_utils.py:36-39,110-131),
@@ -665,9 +692,9 @@ int lmi_letterbox_u8_uniform(const void *src, int batch, int h, int w, int64_t r
   int32_t g[6];
   rc = lmi_letterbox_geometry(h, w, dst_h, dst_w, stretch, g);
   if (rc) return rc;
-  rc = check_frame(src, h, w, row_stride, g[0], g[1], g[2], g[4], dst_h, dst_w, 0);
+  rc = check_frame(src, h, w, row_stride, g[0], g[1], g[2], g[4], dst_h, dst_w, 0, ch);
   if (rc) return rc;
-  LMI_REQUIRE(batch == 1 || (image_stride >= (int64_t)(h - 1) * row_stride + 3LL * w && (image_stride & 15) == 0),
+  LMI_REQUIRE(batch == 1 || (image_stride >= (int64_t)(h - 1) * row_stride + (int64_t)ch * w && (image_stride & 15) == 0),
               batch == 1 ? LMI_ERR_BAD_ARG : LMI_ERR_ALIGNMENT,
               "lmi_letterbox_u8_uniform: image_stride %lld must cover a frame and be a multiple of 16", (long long)image_stride);
   LbParams P{};
@@ -677,9 +704,9 @@ int lmi_letterbox_u8_uniform(const void *src, int batch, int h, int w, int64_t r
   P.new_w = g[0]; P.new_h = g[1]; P.pad_l = g[2]; P.pad_t = g[4];
   P.dst = dst; P.dst_h = dst_h; P.dst_w = dst_w; P.pad_value = pad_value; P.swap_rb = swap_rb ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int p128 = lds_pitch_for(w, g[0], 128), p32 = lds_pitch_for(w, g[0], 32);
-  return dst_dtype == LMI_F32 ? launch_letterbox<float, false>(P, batch, 1, p128, p32, workspace, workspace_bytes, s)
-                              : launch_letterbox<__half, false>(P, batch, 1, p128, p32, workspace, workspace_bytes, s);
+  const int p128 = lds_pitch_for(w, g[0], 128, ch), p32 = lds_pitch_for(w, g[0], 32, ch);
+  return dst_dtype == LMI_F32 ? launch_letterbox<float, false>(P, batch, 1, ch, p128, p32, workspace, workspace_bytes, s)
+                              : launch_letterbox<__half, false>(P, batch, 1, ch, p128, p32, workspace, workspace_bytes, s);
 }
 
 int lmi_preprocess_u8(const void *src, int h, int w, int c, int64_t row_stride, void *dst, int dst_dtype, void *stream) {

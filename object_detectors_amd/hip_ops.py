@@ -116,7 +116,8 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
     """Fused resize + centred pad + channel swap + /255 + NCHW.
 
     frames: a (B,H,W,3) uint8 tensor (uniform batch) or a sequence of (H,W,3) uint8 tensors of any
-    sizes.  Returns (tensor (B,3,dst_h,dst_w), operators) where operators[b] is the list
+    sizes; grey planes go in as (B,H,W,1) / (H,W) / (H,W,1): they are resampled once and written to the three output
+    planes, which is what the callers' GRAY2BGR + resize gives (run_model.py:77-78).  Returns (tensor (B,3,dst_h,dst_w), operators) where operators[b] is the list
     `[{'resize': [new_w,new_h,w,h]}, {'pad': [L,R,T,B]}]` that `revert_to_origin` consumes.
     mode 'cv2': cv2.resize INTER_LINEAR (the callers' default chain); mode 'torch': the reference helpers
     `resize_image` + `fit_im_to_size` (fp32 bilinear, truncating cast; `resize=(H, W)` as the v1 runner's
@@ -130,17 +131,19 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
         raise ValueError(f"letterbox: unknown mode {mode!r}")
     if resize is not None and mode != "torch":
         raise ValueError("letterbox: resize= belongs to mode='torch' (the cv2 flavour derives its geometry from dst_hw)")
-    if mode == "torch" and isinstance(frames, torch.Tensor):
-        if frames.ndim == 3:
+    if isinstance(frames, torch.Tensor):
+        if frames.ndim == 2:
+            frames = frames[None, :, :, None]
+        elif frames.ndim == 3:
             frames = frames.unsqueeze(0)
+    if mode == "torch" and isinstance(frames, torch.Tensor):
         frames = list(frames.unbind(0))   # geometry by the helpers' rules: the descriptor form carries it
     if isinstance(frames, torch.Tensor):
         _need_cuda(frames, "frames")
-        if frames.ndim == 3:
-            frames = frames.unsqueeze(0)
-        if frames.dtype != torch.uint8 or frames.shape[-1] != 3:
-            raise TypeError("letterbox expects uint8 (B,H,W,3)")
-        if frames.stride(3) != 1 or frames.stride(2) != 3 or (frames.shape[0] > 1 and frames.stride(0) % 16) or frames.data_ptr() % 16:
+        if frames.dtype != torch.uint8 or frames.ndim != 4 or frames.shape[-1] not in (1, 3):
+            raise TypeError("letterbox expects uint8 (B,H,W,3) or, for grey planes, (B,H,W,1)")
+        ch = int(frames.shape[-1])
+        if frames.stride(3) != 1 or frames.stride(2) != ch or (frames.shape[0] > 1 and frames.stride(0) % 16) or frames.data_ptr() % 16:
             frames = frames.contiguous()
             if frames.shape[0] > 1 and frames.stride(0) % 16:
                 return letterbox(list(frames.unbind(0)), dst_hw, pad_value, swap_rb, fp16, stretch, out, mode)
@@ -151,7 +154,7 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
             _check_lb_out(out, b, dst_h, dst_w, tdt, frames.device)
         ws = _ws.get(frames.device, "letterbox", int(_L.lmi_letterbox_workspace_bytes(1, dst_h, dst_w)))
         check(_L.lmi_letterbox_u8_uniform(frames.data_ptr(), b, h, w, frames.stride(1), frames.stride(0), out.data_ptr(),
-                                          dst_h, dst_w, ldt, pad_value, int(swap_rb), int(stretch), 0, ws.data_ptr(),
+                                          dst_h, dst_w, ldt, pad_value, int(swap_rb), int(stretch), _lib.LMI_SRC_GRAY if ch == 1 else 0, ws.data_ptr(),
                                           ws.numel(), _stream(frames.device)))
         g = letterbox_geometry(h, w, dst_h, dst_w, stretch)
         ops = [[{"resize": [g[0], g[1], w, h]}, {"pad": [g[2], g[3], g[4], g[5]]}] for _ in range(b)]
@@ -162,11 +165,17 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
     keep = []
     desc = (lmi_frame * len(frames))()
     ops = []
+    ch = None
     for i, f in enumerate(frames):
         _need_cuda(f, f"frames[{i}]")
-        if f.dtype != torch.uint8 or f.ndim != 3 or f.shape[-1] != 3:
-            raise TypeError("letterbox expects uint8 (H,W,3) frames")
-        if f.stride(2) != 1 or f.stride(1) != 3 or f.data_ptr() % 16:
+        if f.ndim == 2:
+            f = f.unsqueeze(-1)
+        if f.dtype != torch.uint8 or f.ndim != 3 or f.shape[-1] not in (1, 3):
+            raise TypeError("letterbox expects uint8 (H,W,3) frames, or grey planes (H,W) / (H,W,1)")
+        if ch is not None and f.shape[-1] != ch:
+            raise ValueError("letterbox: one batch holds either colour frames or grey planes, not both")
+        ch = int(f.shape[-1])
+        if f.stride(2) != 1 or f.stride(1) != ch or f.data_ptr() % 16:
             f = f.contiguous()
             if f.data_ptr() % 16:
                 f = f.clone()
@@ -187,7 +196,8 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
         _check_lb_out(out, len(keep), dst_h, dst_w, tdt, dev)
     ws = _ws.get(dev, "letterbox", int(_L.lmi_letterbox_workspace_bytes(len(keep), dst_h, dst_w)))
     check(_L.lmi_letterbox_u8(C.addressof(desc), ddev.data_ptr(), len(keep), out.data_ptr(), dst_h, dst_w, ldt,
-                              pad_value, int(swap_rb), (2 if torch_threads == 1 else 1) if mode == "torch" else 0, ws.data_ptr(), ws.numel(), _stream(dev)))
+                              pad_value, int(swap_rb), ((2 if torch_threads == 1 else 1) if mode == "torch" else 0) | (_lib.LMI_SRC_GRAY if ch == 1 else 0),
+                              ws.data_ptr(), ws.numel(), _stream(dev)))
     ddev.record_stream(torch.cuda.current_stream(dev))
     return out, ops
 

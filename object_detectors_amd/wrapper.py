@@ -129,7 +129,8 @@ class Yolov8Core:
     def letterbox(self, frames, imgsz=(640, 640), pad_value=114, swap_rb=False, stretch=False):
         """Batch of raw uint8 HWC frames (list of arrays/tensors or a (B,H,W,3) tensor) ->
         ((B,3,h,w) network input, operators per frame).  One fused kernel: cv2-INTER_LINEAR resize,
-        centred pad, optional BGR<->RGB, /255, NCHW."""
+        centred pad, optional BGR<->RGB, /255, NCHW.  Grey planes ((H,W) / (H,W,1) frames, a (B,H,W,1) batch) come out
+        as three equal channels, as the reference runner's GRAY2BGR + resize gives (run_model.py:77-78)."""
         self._require_gpu('letterbox')
         if isinstance(frames, np.ndarray):
             frames = torch.from_numpy(frames)
@@ -339,7 +340,7 @@ class Yolov8Core:
         operator list is needed.  Returns (results dict as `postprocess`, time_info)."""
         time_info = {}
         t0 = time.time()
-        if isinstance(frames, (np.ndarray, torch.Tensor)) and frames.ndim == 3:
+        if isinstance(frames, (np.ndarray, torch.Tensor)) and frames.ndim in (2, 3):   # one frame: (H,W,3), or a grey plane (H,W)
             frames = [frames]
         im, _ = self.letterbox(frames, imgsz, swap_rb=swap_rb)
         time_info['preproc'] = time.time() - t0

@@ -30,3 +30,13 @@ for (h,w,S,B) in [(1080,1920,640,64),(2160,3840,640,64),(480,640,640,64)]:
         ops.letterbox(fs[k[0]],(S,S),pad_value=0,swap_rb=False,mode="torch")
     print(f"{B} x {h}x{w} -> {S}: {timeit(rot):.1f} us", flush=True)
     del fs
+print("grey planes (LMI_SRC_GRAY):")
+for (h,w,S,B) in [(1080,1920,640,64),(2160,3840,640,64),(1080,1920,1280,32)]:
+    fs=[torch.randint(0,256,(B,h,w,1),dtype=torch.uint8,device='cuda') for _ in range(3)]
+    o=torch.empty((B,3,S,S),device='cuda')
+    k=[0]
+    def rot():
+        k[0]=(k[0]+1)%3
+        ops.letterbox(fs[k[0]],(S,S),out=o,pad_value=114)
+    print(f"{B} x {h}x{w} -> {S}: {timeit(rot):.1f} us", flush=True)
+    del fs

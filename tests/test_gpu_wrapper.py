@@ -128,6 +128,27 @@ def test_predict_batch_ragged_frames(models):
         assert res['masks'][i].shape == masks.shape and OM.mask_iou(res['masks'][i], masks) >= 0.999
 
 
+def test_predict_batch_grey_frames_equal_replicated_colour(models):
+    """Grey planes (the runner's GRAY2BGR case, run_model.py:77-78) through predict_batch: same results as the frames
+    replicated to three channels, for a list of planes and for one 2-D frame."""
+    _, seg = models
+    rng = np.random.default_rng(4)
+    planes = [synth.frames_u8(rng, 1, h, w)[0, :, :, 0].copy() for h, w in ((270, 480), (300, 200))]
+    colour = [np.repeat(p[..., None], 3, -1) for p in planes]
+    im_g, ops_g = seg.letterbox(planes, (256, 256))
+    im_c, ops_c = seg.letterbox(colour, (256, 256))
+    assert ops_g == ops_c and torch.equal(im_g, im_c)
+    conf = _conf_for(seg.forward(im_c)[0].cpu().numpy())
+    res_g, _ = seg.predict_batch(planes, conf, imgsz=(256, 256), max_det=30)
+    res_c, _ = seg.predict_batch(colour, conf, imgsz=(256, 256), max_det=30)
+    assert len(res_g['boxes']) == len(res_c['boxes']) == 2
+    for i in range(2):
+        assert np.array_equal(res_g['boxes'][i], res_c['boxes'][i]) and res_g['classes'][i] == res_c['classes'][i]
+        assert np.array_equal(res_g['masks'][i], res_c['masks'][i]) and res_g['masks'][i].shape[1:] == planes[i].shape
+    one, _ = seg.predict_batch(planes[0], conf, imgsz=(256, 256), max_det=30)
+    assert np.array_equal(one['boxes'][0], res_c['boxes'][0])
+
+
 def test_predict_batch_eight_ragged_sizes_one_mask_launch(models):
     """Eight differently sized frames in one batch (the reference's postprocess loops over such a list,
     model.py:215-236): one NMS + finalize chain and ONE mask launch, checked per image against the oracle."""
