@@ -42,6 +42,32 @@ class _WorkspaceCache:
 _ws = _WorkspaceCache()
 
 
+class _DescriptorCache:
+    """Device copies of small descriptor arrays, by content.  A serving loop that letterboxes the same frame buffers
+    again (same pointers, same geometry) hands over byte-identical descriptors: the upload -- a pageable host-to-device
+    copy, ~100 us, more than the kernel -- then happens once.  The first use synchronises its stream so that later calls
+    may read the copy from any stream (and from inside a graph capture, where neither a copy nor a wait is allowed)."""
+
+    def __init__(self, limit: int = 16):
+        self._d = {}
+        self._limit = limit
+
+    def get(self, device: torch.device, raw: bytes) -> torch.Tensor:
+        key = (device.index, raw)
+        t = self._d.pop(key, None)
+        if t is None:
+            t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream(device).synchronize()
+        self._d[key] = t
+        while len(self._d) > self._limit:
+            self._d.pop(next(iter(self._d)))
+        return t
+
+
+_desc = _DescriptorCache()
+
+
 def _stream(device=None) -> int:
     """The current torch stream of `device` (the tensors' device, not whatever device happens to be current)."""
     return torch.cuda.current_stream(device).cuda_stream
@@ -188,8 +214,7 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
         desc[i] = lmi_frame(f.data_ptr(), h, w, f.stride(0), g[0], g[1], g[2], g[4], 0)
         ops.append([{"resize": [g[0], g[1], w, h]}, {"pad": [g[2], g[3], g[4], g[5]]}])
     dev = keep[0].device
-    host = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8)
-    ddev = host.to(dev)
+    ddev = _desc.get(dev, bytes(desc))
     if out is None:
         out = torch.empty((len(keep), 3, dst_h, dst_w), dtype=tdt, device=dev)
     else:
@@ -371,6 +396,9 @@ def scale_coords(det: torch.Tensor, count: torch.Tensor, nkpt: int, ndim: int, m
     return det
 
 
+_MASK_DTYPES = {torch.uint8: LMI_U8, torch.bool: LMI_U8, torch.float32: LMI_F32}
+
+
 def _mask_flags(logits: str, upsample: str) -> int:
     if logits not in ("rows", "mfma") or upsample not in ("split", "single"):
         raise ValueError("process_mask: logits must be 'rows' | 'mfma', upsample 'split' | 'single'")
@@ -424,7 +452,7 @@ def process_mask(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.Tensor,
     _, max_det, stride = det.shape
     h0, w0 = int(orig_hw[0]), int(orig_hw[1])
     _check_window(mh, mw, h0, w0)
-    ldt = {torch.uint8: LMI_U8, torch.float32: LMI_F32}[out_dtype]
+    ldt = _MASK_DTYPES[out_dtype]   # torch.bool: the kernels' 0/1 bytes ARE bools (same storage as uint8)
     capacity = max(int(capacity), 1)
     if out is None:
         out = torch.empty((capacity, h0, w0), dtype=out_dtype, device=proto.device)
@@ -466,7 +494,7 @@ def process_mask_ragged(proto: torch.Tensor, det: torch.Tensor, slot_map: torch.
     _, max_det, stride = det.shape
     if len(sizes) != b or len(counts) != b:
         raise ValueError("process_mask_ragged: one size and one count per image")
-    ldt = {torch.uint8: LMI_U8, torch.float32: LMI_F32}[out_dtype]
+    ldt = _MASK_DTYPES[out_dtype]   # torch.bool: the kernels' 0/1 bytes ARE bools (same storage as uint8)
     desc = (_lib.lmi_mask_image * b)()
     off = 0
     for i, ((h0, w0), n) in enumerate(zip(sizes, counts)):

@@ -72,3 +72,30 @@ def test_gray_torch_flavour_stretch_and_crop(ops):
         a1, _ = ops.letterbox([dev(p)], dst, pad_value=0, mode="torch", resize=resize, torch_threads=1)
         b1, _ = ops.letterbox([dev(np.repeat(p[..., None], 3, -1))], dst, pad_value=0, mode="torch", resize=resize, torch_threads=1)
         assert torch.equal(a1, b1)
+
+
+def _seeds(first):
+    import os
+    return [first] + [10_000 + first + k for k in range(int(os.environ.get("LMI_FUZZ_EXTRA", "0")))]
+
+
+@pytest.mark.parametrize("seed", _seeds(31))
+def test_gray_random_geometries(ops, seed):
+    """random sizes, strides, pads and destinations, both resamplers: grey plane == replicated colour frame"""
+    rng = np.random.default_rng(seed)
+    for it in range(16):
+        n = int(rng.integers(1, 5))
+        sizes = [(int(rng.integers(2, 500)), int(rng.integers(2, 700))) for _ in range(n)]
+        dst = (int(rng.integers(8, 400)), int(rng.integers(8, 400)))
+        planes = [rng.integers(0, 256, s, dtype=np.uint8) for s in sizes]
+        kw = dict(pad_value=int(rng.integers(0, 256)), swap_rb=bool(it & 1), fp16=bool(it & 2), stretch=bool(it & 4))
+        for mode in ("cv2", "torch"):
+            colour = [dev(np.repeat(p[..., None], 3, -1)) for p in planes]
+            try:
+                a, oa = ops.letterbox([dev(p) for p in planes], dst, mode=mode, **kw)
+            except ValueError:   # a frame so thin that its content rounds to zero rows or columns: refused either way
+                with pytest.raises(ValueError):
+                    ops.letterbox(colour, dst, mode=mode, **kw)
+                continue
+            b, ob = ops.letterbox(colour, dst, mode=mode, **kw)
+            assert oa == ob and torch.equal(a, b), (seed, it, mode, sizes, dst)

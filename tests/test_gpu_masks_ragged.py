@@ -152,3 +152,18 @@ def test_fp16_prototypes_equal_the_converted_tensor(ops):
     rc = L.lmi_mask_logits_ex(p_odd.data_ptr(), 1, 32, 41, 41, d.data_ptr(), max_det, 38, m.data_ptr(), s.data_ptr(), 270, 480, None, None,
                               8, ws.data_ptr(), ws.numel(), _lib.LMI_MASK_PROTO_F16, None)
     assert rc == -1 and b"fp16 prototypes" in L.lmi_last_error()
+
+
+def test_bool_masks_share_the_uint8_bytes(ops):
+    """out_dtype=torch.bool: the kernels' 0/1 bytes are torch bools (same storage), uniform and ragged."""
+    rng = np.random.default_rng(64)
+    sizes, counts = [(480, 640), (375, 500)], [3, 4]
+    proto = synth.proto(rng, 2, 32, 160, 160)
+    det, sm, sb = scene(rng, sizes, counts, 8)
+    a = ops.process_mask_ragged(dev(proto), dev(det), dev(sm), dev(sb), sizes, counts, torch.bool)
+    b = ops.process_mask_ragged(dev(proto), dev(det), dev(sm), dev(sb), sizes, counts, torch.uint8)
+    for x, y in zip(a, b):
+        assert x.dtype == torch.bool and torch.equal(x, y.bool()) and torch.equal(x.view(torch.uint8), y)
+    u, _ = ops.process_mask(dev(proto), dev(det), dev(sm), dev(sb), sizes[0], 7, torch.bool)
+    v, _ = ops.process_mask(dev(proto), dev(det), dev(sm), dev(sb), sizes[0], 7, torch.uint8)
+    assert u.dtype == torch.bool and torch.equal(u.view(torch.uint8), v)
