@@ -85,3 +85,24 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.undo()
     importlib.reload(H)   # back to the real library for the tests that follow
     assert H._L is L.load()
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """include/lmi_hip.h through `gcc -std=c99 -pedantic -Werror`, linked against liblmi_hip.so and run: the boundary
+    is a C ABI a cgo / JNI / ctypes binding can sit on (host-only entry points, no GPU needed)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    libdir = os.path.join(ROOT, "object_detectors_amd")
+    exe = str(tmp_path / "abi_c_client")
+    cmd = [gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "abi_c_client.c"), "-o", exe, "-L", libdir, "-llmi_hip", f"-Wl,-rpath,{libdir}",
+           "-Wl,-rpath-link,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "640 360 0 0 140 140" and lines[-1] == "bad argument"
