@@ -82,7 +82,7 @@ int lmi_letterbox_geometry(int h, int w, int dst_h, int dst_w, int stretch, int3
 
 /* one source frame of a ragged batch; the array lives in device memory */
 typedef struct lmi_frame {
-  uint64_t src;        /* [device] uint8 HWC, 3 channels (one with LMI_SRC_GRAY), 16-byte aligned */
+  uint64_t src;        /* [device] uint8 HWC, 3 channels (one with LMI_SRC_GRAY); any byte alignment */
   int32_t h, w;        /* source size */
   int32_t row_stride;  /* bytes between source rows, >= 3*w (>= w with LMI_SRC_GRAY) */
   int32_t new_w, new_h;/* resized content size (lmi_letterbox_geometry) */
@@ -129,7 +129,8 @@ int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, 
                      void *dst, int dst_h, int dst_w, int dst_dtype, int pad_value, int swap_rb,
                      int mode, void *workspace, int64_t workspace_bytes, void *stream);
 
-/* Same, for a batch of equally sized frames stored with a constant image stride: no
+/* Same, for a batch of equally sized frames stored with a constant image stride (any number of bytes that
+ * covers a frame: a packed batch of 375x500 frames, 562500 bytes apart, is read in place): no
  * descriptor array, geometry is derived from (h,w,dst_h,dst_w,stretch) on the host; one table
  * set: workspace >= lmi_letterbox_workspace_bytes(1, dst_h, dst_w).  mode must be LMI_RESIZE_CV2_LINEAR: the
  * geometry derived here is cv2's / ultralytics' (round(), centred pad), not the reference helpers' (int()

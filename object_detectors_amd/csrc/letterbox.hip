@@ -207,6 +207,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
   int h, w, new_w, new_h, pad_l, pad_t;
   long long stride;
   frame_of(P, b, src, h, w, stride, new_w, new_h, pad_l, pad_t);
+  const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);   // the frame's start within its 16-byte chunk
   const int set = P.frames != nullptr ? b : 0;
   const int2 *xt = P.xtab + (size_t)set * P.xw;
   const int4 *yt = P.ytab + (size_t)set * P.dst_h;
@@ -257,11 +258,14 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
   const int nchunk = (span_bytes + 15 + 15) >> 4;              // covers any 0..15 byte alignment shift
   {
     // Range-checked loads are dropped whole when they cross num_records, so the range is the frame
-    // rounded up to the 16-byte chunk size.  The base is 16-byte aligned, hence the rounded end is too and
-    // the last chunk stays inside the page that holds the frame's last byte: no access can fault.
-    const uint32_t frame_bytes = (uint32_t)(((long long)(h - 1) * stride + (long long)CH * w + 15) & ~15LL);
-    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(reinterpret_cast<uintptr_t>(src) & 0xffffffffu));
-    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(reinterpret_cast<uintptr_t>(src) >> 32));
+    // rounded up to the 16-byte chunk size.  The buffer's base is the frame's address rounded DOWN to 16 bytes (a
+    // frame may start at any byte: frame k of a packed batch of 375x500 images does; `mis` shifts every offset),
+    // hence the rounded end is 16-byte aligned too: the first chunk stays inside the page that holds the frame's
+    // first byte and the last one inside the page of its last byte -- no access can fault.
+    const uint32_t frame_bytes = (uint32_t)(((long long)(h - 1) * stride + (long long)CH * w + mis + 15) & ~15LL);
+    const uintptr_t abase = reinterpret_cast<uintptr_t>(src) - mis;
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(abase & 0xffffffffu));
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(abase >> 32));
     const void *ubase = reinterpret_cast<const void *>(((uintptr_t)hi << 32) | lo);
     auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ubase), 0,
                                                   __builtin_amdgcn_readfirstlane(frame_bytes), 0x00020000);
@@ -284,7 +288,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
       }
     }
     if (row >= 0) {
-      const uint32_t goff = (uint32_t)((long long)row * stride + span_b0);
+      const uint32_t goff = (uint32_t)((long long)row * stride + span_b0) + mis;
       const uint32_t aligned = goff & ~15u;
       // KF loads in flight per lane before the first LDS write: the loop is latency-bound otherwise (4K frames need 10
       // chunks per lane: 169.5 us with 4 in flight, 159.3 us with 12).  Loads past the row's span get an out-of-range
@@ -319,8 +323,8 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
     // byte offsets inside the staged rows (the slot's data starts `shift` bytes into its LDS row); every
     // LDS access indexes the one `rows` array so the compiler keeps them as ds_read, not flat loads
     const uint32_t *rw = reinterpret_cast<const uint32_t *>(rows);
-    const int shift0 = (int)(((uint32_t)((long long)ye.x * stride + span_b0)) & 15u);
-    const int shift1 = (int)(((uint32_t)((long long)ye.y * stride + span_b0)) & 15u);
+    const int shift0 = (int)(((uint32_t)((long long)ye.x * stride + span_b0) + mis) & 15u);
+    const int shift1 = (int)(((uint32_t)((long long)ye.y * stride + span_b0) + mis) & 15u);
     const int base0 = (2 * r) * P.pitch + shift0 - span_b0;
     const int base1 = (2 * r + 1) * P.pitch + shift1 - span_b0;
     const int xs_[4] = {xe01.x, xe01.z, xe23.x, xe23.z};
@@ -626,9 +630,8 @@ int check_common(const void *dst, int dst_h, int dst_w, int dst_dtype, int pad_v
 int check_frame(const void *src, int h, int w, long long stride, int new_w, int new_h, int pad_l, int pad_t, int dst_h, int dst_w, int i,
                 int ch, bool may_crop = false) {
   LMI_REQUIRE(src != nullptr, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frame %d: src is NULL", i);
-  LMI_REQUIRE(lmi_is_aligned(src, 16), LMI_ERR_ALIGNMENT, "lmi_letterbox_u8: frame %d: src must be 16-byte aligned", i);
   LMI_REQUIRE(h > 0 && w > 0 && stride >= (long long)ch * w, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frame %d: bad size/stride (%d,%d,%lld)", i, h, w, stride);
-  LMI_REQUIRE((long long)(h - 1) * stride + (long long)ch * w < (1LL << 32) - 16, LMI_ERR_LIMIT, "lmi_letterbox_u8: frame %d larger than 4 GiB", i);
+  LMI_REQUIRE((long long)(h - 1) * stride + (long long)ch * w < (1LL << 32) - 32, LMI_ERR_LIMIT, "lmi_letterbox_u8: frame %d larger than 4 GiB", i);
   // the torch flavour may place the content partly outside the destination (fit_im_to_size crops, centred)
   LMI_REQUIRE(new_w > 0 && new_h > 0 && (may_crop || (pad_l >= 0 && pad_t >= 0 && pad_l + new_w <= dst_w && pad_t + new_h <= dst_h)),
               LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frame %d: content %dx%d at (%d,%d) does not fit %dx%d", i, new_w, new_h, pad_l, pad_t, dst_w, dst_h);
@@ -694,9 +697,8 @@ int lmi_letterbox_u8_uniform(const void *src, int batch, int h, int w, int64_t r
   if (rc) return rc;
   rc = check_frame(src, h, w, row_stride, g[0], g[1], g[2], g[4], dst_h, dst_w, 0, ch);
   if (rc) return rc;
-  LMI_REQUIRE(batch == 1 || (image_stride >= (int64_t)(h - 1) * row_stride + (int64_t)ch * w && (image_stride & 15) == 0),
-              batch == 1 ? LMI_ERR_BAD_ARG : LMI_ERR_ALIGNMENT,
-              "lmi_letterbox_u8_uniform: image_stride %lld must cover a frame and be a multiple of 16", (long long)image_stride);
+  LMI_REQUIRE(batch == 1 || image_stride >= (int64_t)(h - 1) * row_stride + (int64_t)ch * w, LMI_ERR_BAD_ARG,
+              "lmi_letterbox_u8_uniform: image_stride %lld must cover a frame", (long long)image_stride);
   LbParams P{};
   P.frames = nullptr;
   P.src = reinterpret_cast<const uint8_t *>(src);

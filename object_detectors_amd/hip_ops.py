@@ -169,10 +169,8 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
         if frames.dtype != torch.uint8 or frames.ndim != 4 or frames.shape[-1] not in (1, 3):
             raise TypeError("letterbox expects uint8 (B,H,W,3) or, for grey planes, (B,H,W,1)")
         ch = int(frames.shape[-1])
-        if frames.stride(3) != 1 or frames.stride(2) != ch or (frames.shape[0] > 1 and frames.stride(0) % 16) or frames.data_ptr() % 16:
+        if frames.stride(3) != 1 or frames.stride(2) != ch:   # frames may start at any byte and lie any distance apart
             frames = frames.contiguous()
-            if frames.shape[0] > 1 and frames.stride(0) % 16:
-                return letterbox(list(frames.unbind(0)), dst_hw, pad_value, swap_rb, fp16, stretch, out, mode)
         b, h, w, _ = frames.shape
         if out is None:
             out = torch.empty((b, 3, dst_h, dst_w), dtype=tdt, device=frames.device)
@@ -201,10 +199,8 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
         if ch is not None and f.shape[-1] != ch:
             raise ValueError("letterbox: one batch holds either colour frames or grey planes, not both")
         ch = int(f.shape[-1])
-        if f.stride(2) != 1 or f.stride(1) != ch or f.data_ptr() % 16:
+        if f.stride(2) != 1 or f.stride(1) != ch:
             f = f.contiguous()
-            if f.data_ptr() % 16:
-                f = f.clone()
         keep.append(f)
         h, w, _ = f.shape
         if mode == "torch":

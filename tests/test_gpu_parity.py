@@ -101,6 +101,40 @@ def test_letterbox_strided_rows_and_bad_args(ops):
         ops.letterbox(torch.from_numpy(big)[None], (96, 96))
 
 
+def test_letterbox_frames_at_any_byte_address(ops):
+    """Frames are read where they lie: every start address modulo 16 (views into one buffer, no copy), image strides
+    that are not multiples of 16 (a packed batch of 375x500 frames), colour and grey, cv2 and torch resamplers."""
+    rng = np.random.default_rng(16)
+    h, w = 45, 61
+    for ch in (3, 1):
+        frame = synth.frames_u8(rng, 1, h, w)[0][:, :, :ch]
+        n = h * w * ch
+        buf = torch.zeros(16 * (n + 64), dtype=torch.uint8, device="cuda")
+        views = []
+        for k in range(16):
+            start = k * (n + 64) // 16 * 16 + k           # start address = k (mod 16)
+            buf[start:start + n] = dev(frame).reshape(-1)
+            v = buf[start:start + n].view(h, w, ch)
+            assert v.data_ptr() % 16 == k and v.data_ptr() == buf.data_ptr() + start
+            views.append(v)
+        for mode in ("cv2", "torch"):
+            got, _ = ops.letterbox(views, (96, 128), pad_value=9, swap_rb=True, mode=mode)
+            assert all(torch.equal(got[k], got[0]) for k in range(16)), mode
+        col = np.repeat(frame, 3, axis=2) if ch == 1 else frame
+        ref, _ = OC.letterbox_u8(col, 96, 128, pad_value=9, swap_rb=True)
+        got, _ = ops.letterbox(views, (96, 128), pad_value=9, swap_rb=True)
+        assert np.array_equal(bits(got[5].cpu().numpy()), bits(ref))
+    # a packed uniform batch whose frames lie 375*500*3 = 562500 bytes apart (4 mod 16), read in place by the uniform entry
+    frames = synth.frames_u8(rng, 5, 375, 500)
+    d = dev(frames)
+    before = torch.cuda.memory_allocated()
+    got, _ = ops.letterbox(d, (640, 640), pad_value=114)
+    assert torch.cuda.memory_allocated() - before <= got.numel() * 4 + (1 << 20)   # the output (+ a table workspace): no copy of the frames
+    for b in (0, 1, 3):
+        ref, _ = OC.letterbox_u8(frames[b], 640, 640, pad_value=114)
+        assert np.array_equal(bits(got[b].cpu().numpy()), bits(ref)), b
+
+
 def test_letterbox_full_size_closed_forms(ops):
     """BASELINE sizes, checked through size-independent closed forms instead of the slow oracle:
     1080p->640 is an exact x3 (pixel pick), 4K->640 an exact x6 (2x2 box mean)."""
