@@ -35,6 +35,18 @@ static __device__ __align__(256) unsigned char scratch[LMI_NMS_STATIC_BYTES];
 namespace {
 
 constexpr int kSortThreads = 1024;
+constexpr int kNmsWindow = 256;   // sorted candidates one step of the greedy sweep looks at (four per lane of a wave)
+
+#ifdef LMI_NMS_STAMPS
+__device__ unsigned long long g_nms_stamps[64];
+#define NMS_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_nms_stamps[i] = wall_clock64(); } while (0)
+#define NMS_STAMP_SET(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_nms_stamps[i] = (v); } while (0)
+extern "C" int lmi_debug_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nms_stamps), sizeof(g_nms_stamps)); }
+extern "C" int lmi_debug_stamps_clear() { static unsigned long long z[64]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_nms_stamps), z, sizeof(z)); }
+#else
+#define NMS_STAMP(i) do {} while (0)
+#define NMS_STAMP_SET(i, v) do {} while (0)
+#endif
 constexpr int kSortLdsCap = 4096;  // keys sorted inside LDS (32 KiB, so the workgroup can share a CU with other kernels' blocks);
                                    // more candidates than that are sorted in the global workspace
 
@@ -389,8 +401,9 @@ __device__ int gather_candidates(const int *__restrict__ cnt, int nblk, int seg,
 //      the length of the longest suppression chain);
 //   4. the kept candidates' keys are compacted and only THEY are sorted (a few hundred keys at most) for the
 //      score-ordered output and the max_det cut.
-// Falls back (returns false; the key list is untouched) when the extent check fails or a class holds more than 256
-// candidates; the caller does not come here for agnostic NMS, > kCpMaxClasses classes, > 2048 candidates, more
+// Falls back (returns false; the key list is untouched) when the extent check fails, a class holds more than 256
+// candidates, or the largest class is big against the image's candidate count (few large classes: the sorted sweep
+// is cheaper, see the bound below); the caller does not come here for agnostic NMS, > kCpMaxClasses classes, > 2048 candidates, more
 // candidates than max_nms (that cut needs the global order), or too little LDS.
 constexpr int kCpMaxClasses = 128;
 constexpr int kCpWords = 4;   // 64-bit words of a class's member set: classes of up to 256 candidates
@@ -463,6 +476,11 @@ __device__ bool class_parallel_nms(const CpScratch &C, uint64_t *keys, uint64_t 
   }
   __syncthreads();
   if (C.misc[0] > 64 * kCpWords) return false;   // uniform
+  // The pair tests below cost one serial sweep over the LARGEST class per lane (~0.18 us per member measured), the
+  // sorted sweep of the fallback ~0.05 us per candidate of the image: models with a handful of classes (2-5 classes,
+  // 100-250 candidates each) are served faster by the fallback (nc = 3, 425 candidates, largest class 211: 59 us
+  // here against 33 us there), scenes spread over many classes by this path.  Same keeps either way.
+  if (C.misc[0] > max(48, (3 * n) / 10 - 50)) return false;   // uniform
   const int W = (C.misc[0] + 63) >> 6;             // words in use for this image
 
   // grouped keys and class-offset boxes; x-extent of the candidates before the offset
@@ -702,6 +720,30 @@ __device__ void finalize_epilogue(const SortNmsParams &S, int b, int K, const in
   if (tid == 0) F.keep_count[b] = total;
 }
 
+// Position (0..255) of the t-th set bit (t counted from 0, t < number of set bits) of the 256-bit set am[0..3];
+// ac[q] = popcount(am[q]).
+__device__ __forceinline__ int nth_alive(const uint64_t (&am)[4], const int (&ac)[4], int t) {
+  int q = 0;
+  uint64_t w = am[0];
+  if (t >= ac[0]) {
+    t -= ac[0]; q = 1; w = am[1];
+    if (t >= ac[1]) {
+      t -= ac[1]; q = 2; w = am[2];
+      if (t >= ac[2]) { t -= ac[2]; q = 3; w = am[3]; }
+    }
+  }
+  int pos = 0;
+  uint32_t v = (uint32_t)w;
+  int c = __builtin_popcount(v);
+  if (t >= c) { t -= c; pos = 32; v = (uint32_t)(w >> 32); }
+  c = __builtin_popcount(v & 0xffffu); if (t >= c) { t -= c; pos += 16; v >>= 16; }
+  c = __builtin_popcount(v & 0xffu);   if (t >= c) { t -= c; pos += 8; v >>= 8; }
+  c = __builtin_popcount(v & 0xfu);    if (t >= c) { t -= c; pos += 4; v >>= 4; }
+  c = __builtin_popcount(v & 0x3u);    if (t >= c) { t -= c; pos += 2; v >>= 2; }
+  if (t >= (int)(v & 1u)) pos += 1;
+  return 64 * q + pos;
+}
+
 template <typename InT>
 __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams S) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -715,7 +757,7 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
   int *kpos = reinterpret_cast<int *>(karea + md);
   uint64_t *pairmask = reinterpret_cast<uint64_t *>(kpos + md);
   int *supp = reinterpret_cast<int *>(pairmask + 64);
-  int *sK = supp + 64;
+  int *sK = supp + kNmsWindow;
   // sorted class-offset boxes stay in LDS when the candidates fit the LDS sort buffer (no global round trip per chunk)
   float4 *lbox = reinterpret_cast<float4 *>(smem + S.lbox_off);
 
@@ -726,6 +768,7 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
   uint64_t *gkeys = S.keys + (size_t)b * S.P;
   float4 *sbox = S.sbox + (size_t)b * A;
 
+  NMS_STAMP(0);
   // ---- the image's candidates, compact, into LDS (or the global list when they do not fit) ----------------------
   int P2 = 0;
   bool in_lds = true;
@@ -736,7 +779,8 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
     if (S.fin) finalize_epilogue(S, b, 0, nullptr, nullptr, reinterpret_cast<int *>(smem));
     return;
   }
-  if (tid < 64) supp[tid] = 0;
+  NMS_STAMP(1);
+  if (tid < kNmsWindow) supp[tid] = 0;
   if (tid == 0) *sK = 0;
   __syncthreads();
 
@@ -758,11 +802,13 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
     }
   }
 
+  NMS_STAMP(2);
   // ---- otherwise: sort the whole list, decode the sorted candidates' (class-offset) boxes ----------------------------
   const int n_eff = min(n, S.max_nms);
   if (!done) {
     if (in_lds) bitonic_desc_lds(lkeys, P2);
     else bitonic_desc(gkeys, P2);
+    NMS_STAMP(3);
     for (int i = tid; i < n_eff; i += kSortThreads) {
       const uint64_t key = in_lds ? lkeys[i] : gkeys[i];
       const uint32_t anchor = ~(uint32_t)key;
@@ -775,43 +821,98 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
     __syncthreads();
   }
 
-  // ---- greedy NMS in chunks of 64 sorted candidates (agnostic NMS, many classes, a very large class, boxes
-  //      wider than the class offset, or more candidates than the LDS buffers hold) ------------------------------
-  for (int base = 0; !done && base < n_eff && K < S.max_det; base += 64) {
-    const int m = min(64, n_eff - base);
+  // ---- greedy NMS over the sorted list (agnostic NMS, many classes, few but large classes, boxes wider than the
+  //      class offset, or more candidates than the LDS buffers hold).  Every step looks at a WINDOW of the next 256
+  //      candidates: (A) all of them are tested against the boxes kept so far -- whoever is hit is dead for good,
+  //      kept boxes are final --, then the first 64 candidates still alive are compacted into one wave's lanes and
+  //      (B) resolved among themselves exactly (pair masks + fixpoint).  The step consumes the window up to the 65th
+  //      alive candidate (the whole window when at most 64 are alive).  In a dense scene nine candidates in ten die
+  //      in (A) once the first boxes are kept, so the serial steps (each a chain of LDS round trips and three
+  //      barriers) shrink from one per 64 candidates to one per 64 SURVIVORS of (A): 1152 candidates, agnostic:
+  //      18 -> 7 steps. ----------------------------------------------------------------------------------------------
+  NMS_STAMP(4);
+  NMS_STAMP_SET(20, (unsigned long long)clock64());
+#ifdef LMI_NMS_STAMPS
+  unsigned long long acc_a = 0, acc_b = 0, acc_c = 0, acc_n = 0, st_ = 0;
+#define NMS_LAP(acc) do { const unsigned long long now_ = wall_clock64(); acc += now_ - st_; st_ = now_; } while (0)
+#else
+#define NMS_LAP(acc) do {} while (0)
+#endif
+  for (int base = 0; !done && base < n_eff && K < S.max_det;) {
+#ifdef LMI_NMS_STAMPS
+    st_ = wall_clock64();
+#endif
+    const int wn = min(kNmsWindow, n_eff - base);
+    // A: every lane holds four candidates of the window (one per 64-candidate sub-chunk) and every wave walks every
+    // sixteenth kept box, two per iteration so that the LDS broadcasts are issued together: a kept box read from
+    // LDS serves four pair tests.  Most kept boxes cannot meet any candidate (another class -- the class offset
+    // moves it 7680 px away -- or another place): a kept box whose x-extent meets no lane's (xx2 > xx1 is necessary
+    // for inter > 0, exactly) is dropped by one wave-uniform branch before the areas and the division are touched.
+    {
+      float4 wb[4];
+      float wa[4];
+      bool hit[4] = {false, false, false, false};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int wp = 64 * q + lane;
+        wb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wp < wn) wb[q] = in_lds ? lbox[base + wp] : sbox[base + wp];
+        wa[q] = (wb[q].z - wb[q].x) * (wb[q].w - wb[q].y);
+      }
+      constexpr int NW = kSortThreads / 64;
+      int k = wave;
+      for (; k + NW < K; k += 2 * NW) {
+        const float a0 = kx1[k], e0 = kx2[k], c0 = ky1[k], f0 = ky2[k], r0 = karea[k];
+        const float a1 = kx1[k + NW], e1 = kx2[k + NW], c1 = ky1[k + NW], f1 = ky2[k + NW], r1 = karea[k + NW];
+        bool o0 = false, o1 = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          o0 = o0 | (fminf(e0, wb[q].z) > fmaxf(a0, wb[q].x));
+          o1 = o1 | (fminf(e1, wb[q].z) > fmaxf(a1, wb[q].x));
+        }
+        if (__ballot(o0) != 0ull) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) hit[q] = hit[q] | iou_gt(a0, c0, e0, f0, r0, wb[q].x, wb[q].y, wb[q].z, wb[q].w, wa[q], S.iou_thr);
+        }
+        if (__ballot(o1) != 0ull) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) hit[q] = hit[q] | iou_gt(a1, c1, e1, f1, r1, wb[q].x, wb[q].y, wb[q].z, wb[q].w, wa[q], S.iou_thr);
+        }
+      }
+      if (k < K) {
+        const float a0 = kx1[k], e0 = kx2[k], c0 = ky1[k], f0 = ky2[k], r0 = karea[k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hit[q] = hit[q] | iou_gt(a0, c0, e0, f0, r0, wb[q].x, wb[q].y, wb[q].z, wb[q].w, wa[q], S.iou_thr);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (hit[q] && 64 * q + lane < wn) supp[64 * q + lane] = 1;
+    }
+    __syncthreads();
+    NMS_LAP(acc_a);
+
+    // the window's candidates still alive, as four 64-bit sets (every wave forms the same sets: no LDS round trip);
+    // lane t takes the t-th of them
+    uint64_t am[4];
+    int ac[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      am[q] = __ballot(64 * q + lane < wn && supp[64 * q + lane] == 0);
+      ac[q] = __builtin_popcountll(am[q]);
+    }
+    const int alive_n = ac[0] + ac[1] + ac[2] + ac[3];
+    const int m = min(64, alive_n);
+    const int used = alive_n > 64 ? nth_alive(am, ac, 64) : wn;   // wave-uniform; >= 64 in the first case, >= 1 in the second
+    int mypos = 0;
     float4 cb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < m) cb = in_lds ? lbox[base + lane] : sbox[base + lane];
+    if (lane < m) {
+      mypos = nth_alive(am, ac, lane);
+      cb = in_lds ? lbox[base + mypos] : sbox[base + mypos];
+    }
     const float carea = (cb.z - cb.x) * (cb.w - cb.y);
 
-    // A: chunk vs kept boxes, kept index strided over the 16 waves, four kept boxes per iteration so that the LDS
-    // broadcasts are issued together.  Most kept boxes cannot meet any candidate of the chunk (another class --
-    // the class offset moves it 7680 px away -- or another place): a kept box whose x-extent meets no lane's
-    // (xx2 > xx1 is necessary for inter > 0, exactly) is dropped by one wave-uniform branch before the y-extents,
-    // areas and the division are touched.
-    bool hit = false;
-    constexpr int NW = kSortThreads / 64;
-    int k = wave;
-    for (; k + 3 * NW < K; k += 4 * NW) {
-      const float a0 = kx1[k], a1 = kx1[k + NW], a2 = kx1[k + 2 * NW], a3 = kx1[k + 3 * NW];
-      const float e0 = kx2[k], e1 = kx2[k + NW], e2 = kx2[k + 2 * NW], e3 = kx2[k + 3 * NW];
-      const bool o0 = fminf(e0, cb.z) > fmaxf(a0, cb.x), o1 = fminf(e1, cb.z) > fmaxf(a1, cb.x);
-      const bool o2 = fminf(e2, cb.z) > fmaxf(a2, cb.x), o3 = fminf(e3, cb.z) > fmaxf(a3, cb.x);
-      if (__ballot(o0 | o1 | o2 | o3) == 0ull) continue;
-      const bool h0 = iou_gt(a0, ky1[k], e0, ky2[k], karea[k], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
-      const bool h1 = iou_gt(a1, ky1[k + NW], e1, ky2[k + NW], karea[k + NW], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
-      const bool h2 = iou_gt(a2, ky1[k + 2 * NW], e2, ky2[k + 2 * NW], karea[k + 2 * NW], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
-      const bool h3 = iou_gt(a3, ky1[k + 3 * NW], e3, ky2[k + 3 * NW], karea[k + 3 * NW], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
-      hit = hit | h0 | h1 | h2 | h3;
-    }
-    for (; k < K; k += NW) {
-      const float a0 = kx1[k], e0 = kx2[k];
-      if (__ballot(fminf(e0, cb.z) > fmaxf(a0, cb.x)) == 0ull) continue;
-      hit = hit | iou_gt(a0, ky1[k], e0, ky2[k], karea[k], cb.x, cb.y, cb.z, cb.w, carea, S.iou_thr);
-    }
-    if (hit && lane < m) supp[lane] = 1;
-
-    // B: pair masks inside the chunk, by column: pairmask[j] = lanes i < j whose box would suppress j's (same
-    // x-extent shortcut: the boxes of one chunk are mostly of different classes)
+    // B: pair masks among the (up to) 64 alive candidates, by column: pairmask[j] = lanes i < j whose box would
+    // suppress j's (same x-extent shortcut)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int j = __builtin_amdgcn_readfirstlane(wave) * 4 + q;  // wave-uniform: the box of lane j comes by readlane
@@ -828,13 +929,14 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
       if (lane == 0) pairmask[j] = mask;
     }
     __syncthreads();
+    NMS_LAP(acc_b);
 
     if (wave == 0) {
-      // Greedy suppression inside the chunk as a fixpoint: S = candidates kept so far; lane j stays iff it is alive
-      // and no kept i < j suppresses it.  After t rounds the first t lanes are final (by induction on j), so the
-      // loop ends within 64 rounds and a round that changes nothing has reached the greedy answer -- in practice
-      // after the length of the longest suppression chain, 2-5 rounds, instead of one serial step per kept box.
-      const uint64_t alive = __ballot(lane < m && supp[lane] == 0);
+      // Greedy suppression among them as a fixpoint: S = candidates kept so far; lane j stays iff no kept i < j
+      // suppresses it.  After t rounds the first t lanes are final (by induction on j), so the loop ends within 64
+      // rounds and a round that changes nothing has reached the greedy answer -- in practice after the length of the
+      // longest suppression chain, 2-5 rounds, instead of one serial step per kept box.
+      const uint64_t alive = __ballot(lane < m);
       const uint64_t col = pairmask[lane];
       uint64_t keep_set = alive;
       for (int round = 0; round < 65; ++round) {   // 64 rounds settle every lane; the bound is belt and braces
@@ -842,7 +944,7 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
         if (next == keep_set) break;
         keep_set = next;
       }
-      // at most max_det rows in all: the first (max_det - K) kept lanes of this chunk
+      // at most max_det rows in all: the first (max_det - K) kept lanes of this step
       const int rank = __builtin_popcountll(keep_set & ((1ull << lane) - 1ull));
       const uint64_t keepm = __ballot(((keep_set >> lane) & 1ull) && K + rank < S.max_det);
       const int Kl = K + __builtin_popcountll(keepm);
@@ -850,15 +952,27 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
         const int idx = K + __builtin_popcountll(keepm & ((1ull << lane) - 1ull));
         kx1[idx] = cb.x; ky1[idx] = cb.y; kx2[idx] = cb.z; ky2[idx] = cb.w;
         karea[idx] = carea;
-        kpos[idx] = base + lane;
+        kpos[idx] = base + mypos;
       }
-      supp[lane] = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) supp[64 * q + lane] = 0;   // every wave read its flags before the barrier above
       if (lane == 0) *sK = Kl;
     }
     __syncthreads();
     K = *sK;
+    base += used;
+    NMS_LAP(acc_c);
+#ifdef LMI_NMS_STAMPS
+    if (acc_n < 10) { NMS_STAMP_SET(30 + acc_n, acc_a); NMS_STAMP_SET(40 + acc_n, acc_b); NMS_STAMP_SET(50 + acc_n, (unsigned long long)K); }
+    acc_n += 1;
+#endif
   }
 
+#ifdef LMI_NMS_STAMPS
+  NMS_STAMP_SET(10, acc_a); NMS_STAMP_SET(11, acc_b); NMS_STAMP_SET(12, acc_c); NMS_STAMP_SET(13, acc_n);
+#endif
+  NMS_STAMP(5);
+  NMS_STAMP_SET(21, (unsigned long long)clock64());
   // ---- emit rows: x1,y1,x2,y2 (no class offset), conf, cls, coef... ---------------------------------
   if (tid == 0) S.out_count[b] = K;
   const int row = 6 + S.nm;
@@ -886,6 +1000,7 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
     od[e] = v;
     if (col == 0) S.out_anchor[(size_t)b * S.max_det + t] = (int)anchor;
   }
+  NMS_STAMP(6);
   if (S.fin) {
     __syncthreads();   // every reader of the sort buffers is done: the epilogue reuses the start of the LDS
     finalize_epilogue(S, b, K, kpos, in_lds ? lkeys : gkeys, reinterpret_cast<int *>(smem));
@@ -1249,7 +1364,7 @@ static std::mutex g_nms_dev_mutex;
 static NmsDeviceState g_nms_dev[kMaxDevices];
 
 constexpr size_t nms_lds_small(int lds_keys, int max_det) {
-  return (size_t)lds_keys * 8 + 4 * 6 * (size_t)((max_det + 1) & ~1) + 64 * 8 + 64 * 4 + 16;
+  return (size_t)lds_keys * 8 + 4 * 6 * (size_t)((max_det + 1) & ~1) + 64 * 8 + kNmsWindow * 4 + 16;
 }
 constexpr size_t nms_lds_rot_head(int lds_keys, int max_det) { return (size_t)lds_keys * 8 + 4 * (size_t)((max_det + 1) & ~1) + 4 * 17 + 16; }
 constexpr size_t kNmsLdsMax = ((nms_lds_small(kSortLdsCap, LMI_MAX_DET_CAP) + 15) & ~(size_t)15) + (size_t)kSortLdsCap * 16 + kGatherLds;

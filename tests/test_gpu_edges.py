@@ -318,6 +318,10 @@ def test_nms_class_parallel_path_boundaries(ops, seed):
         dict(sizes=[40, 30, 20], big=9000.0), dict(sizes=[40, 30, 20], spread=7700.0),
         dict(sizes=[200, 100, 50], max_det=7), dict(sizes=[300, 300, 300, 300], max_det=300),
         dict(sizes=[63, 1, 64, 2, 65]), dict(sizes=[1]), dict(sizes=[2, 0, 0, 1]),
+        # the kernel leaves the decomposition to the sorted sweep when the largest class exceeds max(48, 0.3 n - 50)
+        # (few, large classes: cheaper there): enough other candidates keep the 2-, 3- and 4-word bit rows in use
+        dict(sizes=[65] + [20] * 20), dict(sizes=[130] + [24] * 20), dict(sizes=[256] + [26] * 30), dict(sizes=[257] + [26] * 30),
+        dict(sizes=[89] + [20] * 20), dict(sizes=[90] + [20] * 20),   # n = 489 / 490: the bound is 96 / 97
     ]
     for ci, cs in enumerate(cases):
         sizes = cs["sizes"]
