@@ -19,8 +19,9 @@ def timeit(fn, n=15):
 
 
 g = torch.Generator(device="cuda").manual_seed(0)
+LB = "nolb" not in sys.argv
 print("-- letterbox flavours, 64 frames -> 640x640 (us per launch; bytes = source + output)")
-for (h, w) in [(1080, 1920), (750, 1000), (375, 500), (2160, 3840)]:
+for (h, w) in ([(1080, 1920), (750, 1000), (375, 500), (2160, 3840)] if LB else []):
     f = torch.randint(0, 256, (64, h, w, 3), dtype=torch.uint8, device="cuda", generator=g)
     o32 = torch.empty((64, 3, 640, 640), device="cuda"); o16 = torch.empty((64, 3, 640, 640), device="cuda", dtype=torch.float16)
     fl = list(f.unbind(0))
