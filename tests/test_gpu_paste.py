@@ -30,7 +30,8 @@ def soft_masks(rng, n, s):
     return np.clip(out, 0, 1).astype(F32)
 
 
-@pytest.mark.parametrize("n,s,h,w", [(7, 28, 480, 640), (3, 28, 101, 67), (40, 28, 1080, 1920), (2, 14, 64, 64)])
+@pytest.mark.parametrize("n,s,h,w", [(7, 28, 480, 640), (3, 28, 101, 67), (40, 28, 1080, 1920), (2, 14, 64, 64),
+                                       (9, 28, 270, 479), (5, 28, 53, 17), (4, 28, 48, 20), (6, 28, 33, 16), (12, 28, 1080, 1916)])
 def test_paste_masks_vs_torch_grid_sample(n, s, h, w):
     from postprocess_utils.mask_utils import rescale_masks
     rng = np.random.default_rng(n * 7 + s)
