@@ -337,3 +337,22 @@ def test_nms_class_parallel_path_boundaries(ops, seed):
             tag = f"case {ci} sizes={sizes[:6]} iou={iou}"
             assert anchor[0, :n].cpu().numpy().tolist() == ra.tolist(), tag
             assert n == 0 or np.abs(det[0, :n].cpu().numpy() - rd).max() <= 1e-3, tag
+
+
+@pytest.mark.parametrize("seed", sweep_seeds(1212))
+def test_nms_sorted_sweep_windows(ops, seed):
+    """The sweep over the sorted list (agnostic NMS; per-class NMS with few, large classes, which the class-parallel
+    path hands over): windows of 256 candidates, of which the first 64 still alive are resolved per step.  Scenes that
+    leave fewer / more than 64 alive in a window, more than one window, a max_det cut inside a step, one class only."""
+    rng = np.random.default_rng(seed)
+    for nc, objects, agn, md in [(1, 40, False, 300), (2, 100, False, 300), (3, 15, False, 300), (80, 110, True, 300),
+                                 (5, 60, True, 300), (2, 100, True, 37), (4, 150, False, 64)]:
+        p = synth.head(rng, 2, nc, 0, 320, objects, cluster=(6, 16))
+        det, count, anchor = ops.nms_v8(dev(p), 0.25, 0.45, agnostic=agn, max_det=md, nc=nc)
+        torch.cuda.synchronize()
+        ref = ON.non_max_suppression(p, 0.25, 0.45, agnostic=agn, max_det=md, nc=nc)
+        for b, (rd, ra) in enumerate(ref):
+            n = int(count[b])
+            tag = f"nc={nc} objects={objects} agnostic={agn} max_det={md} image {b}"
+            assert anchor[b, :n].cpu().numpy().tolist() == ra.tolist(), tag
+            assert n == 0 or np.array_equal(det[b, :n].cpu().numpy(), rd.astype(F32)), tag
