@@ -542,7 +542,7 @@ int lmi_paste_masks(const float *masks, int64_t n, int mask_h, int mask_w, const
   P.H = img_h; P.W = img_w; P.threshold = threshold;
   dim3 grid(((img_w + 15) / 16 + 63) / 64, (img_h + 3) / 4, (unsigned)n);
   LMI_REQUIRE(grid.y <= 65535, LMI_ERR_LIMIT, "lmi_paste_masks: image height %d too large", img_h);
-  if ((img_w & 15) != 0 && img_w >= 16 && lmi_is_aligned(out, 16)) {   // rows that are not whole chunks: chunks by absolute address
+  if ((img_w & 15) != 0 && img_w >= 16 && (long long)img_h * img_w < (1LL << 31) && lmi_is_aligned(out, 16)) {   // rows that are not whole chunks: chunks by absolute address
     const long long chunks = ((long long)n * img_h * img_w + 15) / 16;
     const long long blocks = (chunks + 255) / 256;
     LMI_REQUIRE(blocks <= 0x7fffffffLL, LMI_ERR_LIMIT, "lmi_paste_masks: output too large");
