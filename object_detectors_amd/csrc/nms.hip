@@ -902,7 +902,6 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
     }
     const int alive_n = ac[0] + ac[1] + ac[2] + ac[3];
     const int m = min(64, alive_n);
-    const int used = alive_n > 64 ? nth_alive(am, ac, 64) : wn;   // wave-uniform; >= 64 in the first case, >= 1 in the second
     int mypos = 0;
     float4 cb = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lane < m) {
@@ -956,11 +955,14 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) supp[64 * q + lane] = 0;   // every wave read its flags before the barrier above
-      if (lane == 0) *sK = Kl;
+      // the step consumes the window up to the 65th alive candidate (>= 64 positions), all of it when at most 64
+      // are alive (>= 1): found by wave 0 alone, the other waves read it with K
+      const int used = alive_n > 64 ? nth_alive(am, ac, 64) : wn;
+      if (lane == 0) { sK[0] = Kl; sK[1] = used; }
     }
     __syncthreads();
-    K = *sK;
-    base += used;
+    K = sK[0];
+    base += sK[1];
     NMS_LAP(acc_c);
 #ifdef LMI_NMS_STAMPS
     if (acc_n < 10) { NMS_STAMP_SET(30 + acc_n, acc_a); NMS_STAMP_SET(40 + acc_n, acc_b); NMS_STAMP_SET(50 + acc_n, (unsigned long long)K); }
