@@ -364,6 +364,7 @@ struct UpParams {
   int lstride;             // floats per slot in `logits`
   int rows_per_block;
   int lds_rows;  // logits rows the LDS buffer can hold
+  int strips;    // row strips per slot: the grid is one-dimensional, block = slot * strips + strip (grid.y would stop at 65535 slots)
   const int4 *table;  // split path: per-slot pixel ranges of the box {xa, xb, ya, yb}
   int *overflow;
 };
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(256) void mask_zero_fill_kernel(const int *__restri
     reinterpret_cast<unsigned char *>(out)[(n << 4) + threadIdx.x] = 0;
 }
 
-// Second pass of the split path: the chunks that meet a slot's box, and nothing else.  grid: x = row strips, y = slot.
+// Second pass of the split path: the chunks that meet a slot's box, and nothing else.  grid: one workgroup per (slot, row strip), slot-major.
 // Every lane owns one 16-byte chunk column of the box and walks down the strip's box rows, so the horizontal
 // weights of its pixels are computed once and all lanes of a wave have work (a lane-per-chunk sweep over whole rows
 // leaves ~3/4 of the lanes idle on boxes ~1/7 of the frame wide).  Same arithmetic as mask_upsample_kernel.
@@ -524,11 +525,12 @@ __global__ __launch_bounds__(256, 4) void mask_box_kernel(UpParams U) {   // 4 w
   __shared__ int2 rowtab[256];   // per strip row: {upper | lower << 16 source row, fp32 bits of the lower row's weight}
   float *L = reinterpret_cast<float *>(smem);
 
-  const long long slot = blockIdx.y;
+  const unsigned slot_u = blockIdx.x / (unsigned)U.strips, strip = blockIdx.x - slot_u * (unsigned)U.strips;
+  const long long slot = slot_u;
   if (slot >= U.slot_base[U.batch]) return;   // beyond the live slots (the grid spans the buffer's capacity)
   if (slot >= U.capacity) return;
   const int4 t = U.table[slot];               // all zero for a box that holds no pixel
-  const int ra = max((int)blockIdx.x * U.rows_per_block, t.z), rb = min(((int)blockIdx.x + 1) * U.rows_per_block, t.w);
+  const int ra = max((int)strip * U.rows_per_block, t.z), rb = min(((int)strip + 1) * U.rows_per_block, t.w);
   if (ra >= rb) return;           // most workgroups: no row of the box in this strip
   const int b = U.M.images ? slot_image(U, slot) : 0;
   const MaskGeom g = image_geom(U.M, b);
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(256, 4) void mask_box_kernel(UpParams U) {   // 4 w
   }
 }
 
-// grid: x = row strips, y = slot
+// grid: one workgroup per (slot, row strip), slot-major
 template <typename OutT>
 __global__ __launch_bounds__(256) void mask_upsample_kernel(UpParams U) {
   using MO = MaskOut<OutT>;
@@ -661,9 +663,10 @@ __global__ __launch_bounds__(256) void mask_upsample_kernel(UpParams U) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *L = reinterpret_cast<float *>(smem);
 
-  const long long slot = blockIdx.y;
+  const unsigned slot_u = blockIdx.x / (unsigned)U.strips, strip = blockIdx.x - slot_u * (unsigned)U.strips;
+  const long long slot = slot_u;
   const int total = U.slot_base[U.batch];
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && U.overflow)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && U.overflow)
     *U.overflow = total > U.capacity ? (int)(total - U.capacity) : 0;  // survivors that did not fit
   if (slot >= total || slot >= U.capacity) return;
   const int e = U.slot_map[slot];
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(256) void mask_upsample_kernel(UpParams U) {
   OutT *out = reinterpret_cast<OutT *>(U.out) + off;
   const bool weights4 = H0 + W0 <= 128;   // aten's kernel choice (oracle/geometry.py:aten_linear_variant)
 
-  const int y_begin = blockIdx.x * U.rows_per_block;
+  const int y_begin = (int)strip * U.rows_per_block;
   if (y_begin >= H0) return;              // ragged batch: the grid spans the tallest frame
   const int y_end = min(y_begin + U.rows_per_block, H0);
   // rows of this strip that intersect the box: y >= by1 && y < by2
@@ -780,7 +783,7 @@ int mask_check_common(const char *fn, int batch, int nm, int mh, int mw, int h0,
   LMI_REQUIRE(nm == LMI_MAX_MASK_DIM, LMI_ERR_LIMIT, "%s: nm=%d, only %d prototype channels are supported", fn, nm, LMI_MAX_MASK_DIM);
   LMI_REQUIRE(batch > 0 && batch <= 65535 && mh > 0 && mw > 0 && max_det > 0 && det_stride >= 6 + nm, LMI_ERR_BAD_ARG,
               "%s: bad shape batch=%d proto=%dx%d max_det=%d det_stride=%d", fn, batch, mh, mw, max_det, det_stride);
-  LMI_REQUIRE(capacity_masks > 0 && capacity_masks <= 65535, LMI_ERR_LIMIT, "%s: capacity_masks %lld not in 1..65535", fn, (long long)capacity_masks);
+  LMI_REQUIRE(capacity_masks > 0 && capacity_masks <= (int64_t)65535 * 1024, LMI_ERR_LIMIT, "%s: capacity_masks %lld not in 1..%lld", fn, (long long)capacity_masks, (long long)65535 * 1024);
   LMI_REQUIRE((images_host == nullptr) == (images_dev == nullptr), LMI_ERR_BAD_ARG, "%s: images_host and images_dev go together", fn);
   C.M.images = images_dev;
   C.max_h0 = 0; C.max_ww = 0; C.max_wh = 0; C.max_ratio = 0.0; C.separable = true; C.chunked = true; C.end_elems = 0;
@@ -895,7 +898,7 @@ int lmi_mask_upsample_ex(void *workspace, int batch, int nm, int mh, int mw, con
   U.batch = batch; U.max_det = max_det; U.det_stride = det_stride; U.capacity = capacity_masks; U.out_elems = out_elems; U.M = C.M;
   U.lstride = mh * mw; U.overflow = overflow;
   U.table = reinterpret_cast<int4 *>(reinterpret_cast<char *>(workspace) + align_up((size_t)capacity_masks * mh * mw * sizeof(float), 256));
-  U.rows_per_block = 0; U.lds_rows = 0;
+  U.rows_per_block = 0; U.lds_rows = 0; U.strips = 1;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
   // Split path: zeros for every live slot at the memset rate -- one workgroup per
@@ -911,7 +914,9 @@ int lmi_mask_upsample_ex(void *workspace, int batch, int nm, int mh, int mw, con
     rc = up_strip(C, U, 256, 1);
     if (rc) return rc;
     const size_t lds = (size_t)U.lds_rows * (C.max_ww + 1) * sizeof(float);
-    dim3 grid((C.max_h0 + U.rows_per_block - 1) / U.rows_per_block, (unsigned)capacity_masks);
+    U.strips = (C.max_h0 + U.rows_per_block - 1) / U.rows_per_block;
+    LMI_REQUIRE((long long)U.strips * capacity_masks <= 0x7fffffffLL, LMI_ERR_LIMIT, "%s: %lld slots x %d row strips exceed the grid", fn, (long long)capacity_masks, U.strips);
+    dim3 grid((unsigned)((long long)U.strips * capacity_masks));
     if (out_dtype == LMI_U8) {
       if (C.chunked) hipLaunchKernelGGL((mask_box_kernel<uint8_t, true>), grid, dim3(256), lds, s, U);
       else hipLaunchKernelGGL((mask_box_kernel<uint8_t, false>), grid, dim3(256), lds, s, U);
@@ -924,7 +929,9 @@ int lmi_mask_upsample_ex(void *workspace, int batch, int nm, int mh, int mw, con
   rc = up_strip(C, U, 16, 0);
   if (rc) return rc;
   const size_t lds = (size_t)U.lds_rows * C.max_ww * sizeof(float);
-  dim3 ugrid((C.max_h0 + U.rows_per_block - 1) / U.rows_per_block, (unsigned)capacity_masks);
+  U.strips = (C.max_h0 + U.rows_per_block - 1) / U.rows_per_block;
+  LMI_REQUIRE((long long)U.strips * capacity_masks <= 0x7fffffffLL, LMI_ERR_LIMIT, "%s: %lld slots x %d row strips exceed the grid", fn, (long long)capacity_masks, U.strips);
+  dim3 ugrid((unsigned)((long long)U.strips * capacity_masks));
   if (out_dtype == LMI_U8) hipLaunchKernelGGL(mask_upsample_kernel<uint8_t>, ugrid, dim3(256), lds, s, U);
   else hipLaunchKernelGGL(mask_upsample_kernel<float>, ugrid, dim3(256), lds, s, U);
   return lmi_check_launch("mask_upsample_kernel");
