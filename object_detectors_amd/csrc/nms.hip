@@ -37,15 +37,15 @@ namespace {
 constexpr int kSortThreads = 1024;
 constexpr int kNmsWindow = 256;   // sorted candidates one step of the greedy sweep looks at (four per lane of a wave)
 
+// Measurement builds only (-DLMI_NMS_STAMPS, scratch/nms_stamps.py): wall-clock stamps of workgroup 0 at the phase
+// boundaries of nms_sort_suppress.  The product library is built without it: the macro is empty, nothing is exported.
 #ifdef LMI_NMS_STAMPS
 __device__ unsigned long long g_nms_stamps[64];
 #define NMS_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_nms_stamps[i] = wall_clock64(); } while (0)
-#define NMS_STAMP_SET(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_nms_stamps[i] = (v); } while (0)
 extern "C" int lmi_debug_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nms_stamps), sizeof(g_nms_stamps)); }
 extern "C" int lmi_debug_stamps_clear() { static unsigned long long z[64]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_nms_stamps), z, sizeof(z)); }
 #else
 #define NMS_STAMP(i) do {} while (0)
-#define NMS_STAMP_SET(i, v) do {} while (0)
 #endif
 constexpr int kSortLdsCap = 4096;  // keys sorted inside LDS (32 KiB, so the workgroup can share a CU with other kernels' blocks);
                                    // more candidates than that are sorted in the global workspace
@@ -831,17 +831,7 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
   //      barriers) shrink from one per 64 candidates to one per 64 SURVIVORS of (A): 1152 candidates, agnostic:
   //      18 -> 7 steps. ----------------------------------------------------------------------------------------------
   NMS_STAMP(4);
-  NMS_STAMP_SET(20, (unsigned long long)clock64());
-#ifdef LMI_NMS_STAMPS
-  unsigned long long acc_a = 0, acc_b = 0, acc_c = 0, acc_n = 0, st_ = 0;
-#define NMS_LAP(acc) do { const unsigned long long now_ = wall_clock64(); acc += now_ - st_; st_ = now_; } while (0)
-#else
-#define NMS_LAP(acc) do {} while (0)
-#endif
   for (int base = 0; !done && base < n_eff && K < S.max_det;) {
-#ifdef LMI_NMS_STAMPS
-    st_ = wall_clock64();
-#endif
     const int wn = min(kNmsWindow, n_eff - base);
     // A: every lane holds four candidates of the window (one per 64-candidate sub-chunk) and every wave walks every
     // sixteenth kept box, two per iteration so that the LDS broadcasts are issued together: a kept box read from
@@ -889,7 +879,6 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
         if (hit[q] && 64 * q + lane < wn) supp[64 * q + lane] = 1;
     }
     __syncthreads();
-    NMS_LAP(acc_a);
 
     // the window's candidates still alive, as four 64-bit sets (every wave forms the same sets: no LDS round trip);
     // lane t takes the t-th of them
@@ -928,7 +917,6 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
       if (lane == 0) pairmask[j] = mask;
     }
     __syncthreads();
-    NMS_LAP(acc_b);
 
     if (wave == 0) {
       // Greedy suppression among them as a fixpoint: S = candidates kept so far; lane j stays iff no kept i < j
@@ -963,18 +951,9 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
     __syncthreads();
     K = sK[0];
     base += sK[1];
-    NMS_LAP(acc_c);
-#ifdef LMI_NMS_STAMPS
-    if (acc_n < 10) { NMS_STAMP_SET(30 + acc_n, acc_a); NMS_STAMP_SET(40 + acc_n, acc_b); NMS_STAMP_SET(50 + acc_n, (unsigned long long)K); }
-    acc_n += 1;
-#endif
   }
 
-#ifdef LMI_NMS_STAMPS
-  NMS_STAMP_SET(10, acc_a); NMS_STAMP_SET(11, acc_b); NMS_STAMP_SET(12, acc_c); NMS_STAMP_SET(13, acc_n);
-#endif
   NMS_STAMP(5);
-  NMS_STAMP_SET(21, (unsigned long long)clock64());
   // ---- emit rows: x1,y1,x2,y2 (no class offset), conf, cls, coef... ---------------------------------
   if (tid == 0) S.out_count[b] = K;
   const int row = 6 + S.nm;

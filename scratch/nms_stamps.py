@@ -19,5 +19,4 @@ for objects, cluster, nc, agn, tag in [(40, (5, 16), 80, False, "typical per-cla
         if it >= 10: acc += np.array(list(buf), dtype=np.float64)
     t = acc / 20
     us = lambda a, b: (t[b] - t[a]) * 10 / 1000
-    print(f"{tag}: gather {us(0,1):.1f}  cp {us(1,2):.1f}  sort {us(2,3):.1f}  boxes {us(3,4):.1f}  sweep {us(4,5):.1f} [steps {t[13]:.1f}: A {t[10]/100:.1f}  alive+B {t[11]/100:.1f}  resolve {t[12]/100:.1f}]  emit {us(5,6):.1f}  total {us(0,6):.1f} us; shader clock during the sweep {(t[21]-t[20])/max(us(4,5),1e-9):.0f} MHz")
-    print("   cumulative A per step (us):", " ".join(f"{t[30+i]/100:.1f}" for i in range(10)), "| alive+B:", " ".join(f"{t[40+i]/100:.1f}" for i in range(10)), "| K after step:", " ".join(f"{t[50+i]:.0f}" for i in range(10)))
+    print(f"{tag}: gather {us(0,1):.1f}  class-parallel {us(1,2):.1f}  sort {us(2,3):.1f}  boxes {us(3,4):.1f}  sweep {us(4,5):.1f}  emit {us(5,6):.1f}  total {us(0,6):.1f} us  (sort / boxes / sweep only on the sorted path)")
