@@ -325,8 +325,93 @@ constexpr int kGatherChunk = 256;   // segments whose prefix is held in LDS at a
 constexpr int kRotQueue = 128;      // rotated NMS: near pairs a wave queues before it evaluates 64 of them
 constexpr size_t kGatherLds = sizeof(int) * (2 * kGatherChunk + 32);   // gather_candidates' scratch, behind the box buffer
 
+// More candidates than the LDS buffers hold (validation-style thresholds: every anchor a candidate).  The sweep stops
+// at max_det keeps, so the whole list is rarely needed: top_keys leaves the (at most) `cap` candidates with the LARGEST
+// keys in lkeys, in any order -- the head of the sorted list, exactly, since keys are unique -- found by a radix
+// histogram of the score bits (12 bits, then 12 more inside the boundary bin) instead of a sort.  The caller sorts and
+// sweeps them in LDS; only if that ends short of max_det keeps does it come back for the whole list (global-memory
+// sort, ~400 us).  hist: LDS, see kTopBins.  Returns the number of keys taken (0: the cut fell on a run of more
+// than `cap` keys with equal leading 24 score bits -- nothing copied, take the whole list).  All lanes call this.
+constexpr int kTopBins = 4096;   // hist: kTopBins + 4 + kSortThreads / 64 ints
+
+// smallest bin c with (keys in bins >= c) <= budget; res[0] = c (kTopBins: not even the last bin fits), res[1] = that count
+__device__ void suffix_cut(const int *hist, int budget, int *res) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = kSortThreads / 64;
+  constexpr int PER = kTopBins / kSortThreads;
+  int *wsum = res + 4;   // NW ints
+  int h[PER], own = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { h[k] = hist[PER * tid + k]; own += h[k]; }
+  int incl = own;        // inclusive suffix over the lanes of the wave (lanes above me)
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int u = __shfl_down(incl, d);
+    if (lane + d < 64) incl += u;
+  }
+  if (lane == 0) wsum[wave] = incl;
+  __syncthreads();
+  int above = incl - own;
+  for (int w = wave + 1; w < NW; ++w) above += wsum[w];
+  // bins of this thread from the top down
+  int sfx = above;
+#pragma unroll
+  for (int k = PER - 1; k >= 0; --k) {
+    sfx += h[k];                                   // S(c), c = PER * tid + k
+    const int c = PER * tid + k;
+    const int below = c == 0 ? 0 : (k > 0 ? h[k - 1] : hist[c - 1]);
+    if (sfx <= budget && (c == 0 || sfx + below > budget)) { res[0] = c; res[1] = sfx; }
+  }
+  if (tid == kSortThreads - 1 && h[PER - 1] > budget) { res[0] = kTopBins; res[1] = 0; }
+  __syncthreads();
+}
+
+__device__ int top_keys(const int *__restrict__ cnt, int nblk, int seg, int cap, uint64_t *lkeys, const uint64_t *gkeys, int *hist) {
+  const int tid = threadIdx.x;
+  const int shift = __ffs(seg) - 1, slots = nblk << shift;
+  int *res = hist + kTopBins;   // [0] cut bin, [1] keys at and above it, [2] copy counter, [4..] suffix_cut's wave sums
+  int taken = 0;
+  unsigned long long T = 0ull;  // keys whose score word is >= T are taken (2^32: none)
+  int bb = 0;                   // boundary bin of level 0
+  for (int level = 0; level < 2; ++level) {
+    for (int i = tid; i < kTopBins; i += kSortThreads) hist[i] = 0;
+    __syncthreads();
+    for (int e = tid; e < slots; e += kSortThreads) {
+      if ((e & (seg - 1)) < cnt[e >> shift]) {
+        const uint32_t hi = (uint32_t)(gkeys[e] >> 32);
+        if (level == 0) atomicAdd(&hist[hi >> 20], 1);
+        else if ((int)(hi >> 20) == bb) atomicAdd(&hist[(hi >> 8) & 0xfffu], 1);
+      }
+    }
+    __syncthreads();
+    suffix_cut(hist, cap - taken, res);
+    const int c = res[0], got = res[1];
+    __syncthreads();            // res is rewritten by the next level
+    if (level == 0) {
+      taken = got;
+      T = (unsigned long long)c << 20;
+      bb = c - 1;               // c >= 1: all the keys together exceed cap
+      if (taken >= cap / 2 || bb < 0) break;
+    } else if (c < kTopBins) {
+      taken += got;
+      T = ((unsigned long long)bb << 20) | ((unsigned long long)c << 8);
+    }
+  }
+  if (taken == 0) return 0;
+  if (tid == 0) res[2] = 0;
+  __syncthreads();
+  for (int e = tid; e < slots; e += kSortThreads) {
+    if ((e & (seg - 1)) < cnt[e >> shift]) {
+      const uint64_t key = gkeys[e];
+      if ((unsigned long long)(uint32_t)(key >> 32) >= T) lkeys[atomicAdd(&res[2], 1)] = key;
+    }
+  }
+  __syncthreads();
+  return res[2];
+}
+
 __device__ int gather_candidates(const int *__restrict__ cnt, int nblk, int seg, int A, int lds_keys, uint64_t *lkeys, uint64_t *gkeys,
-                                 uint64_t *gtmp, int *scr, int &P2, bool &in_lds) {
+                                 uint64_t *gtmp, int *scr, int &P2, bool &in_lds, int *hist, int &n_total) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = kSortThreads / 64;
   int *wtot = scr, *ccnt = scr + 32, *cpre = scr + 32 + kGatherChunk;
@@ -340,7 +425,18 @@ __device__ int gather_candidates(const int *__restrict__ cnt, int nblk, int seg,
   for (int w = 0; w < NW; ++w) n += wtot[w];
   n = min(n, A);
   __syncthreads();
+  n_total = n;
   if (n == 0) return 0;
+  if (n > lds_keys && hist != nullptr) {   // the head of the list only (see top_keys); hist == nullptr: the caller wants all of it
+    const int m = top_keys(cnt, nblk, seg, lds_keys, lkeys, gkeys, hist);
+    if (m > 0) {
+      P2 = next_pow2(m);
+      in_lds = true;
+      for (int i = m + tid; i < P2; i += kSortThreads) lkeys[i] = 0ull;
+      __syncthreads();
+      return m;
+    }
+  }
   P2 = next_pow2(n);
   in_lds = P2 <= lds_keys;
   uint64_t *dst = in_lds ? lkeys : gtmp;
@@ -770,190 +866,209 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
 
   NMS_STAMP(0);
   // ---- the image's candidates, compact, into LDS (or the global list when they do not fit) ----------------------
-  int P2 = 0;
+  int P2 = 0, n_total = 0;
   bool in_lds = true;
-  const int n = gather_candidates(S.blk_count + (size_t)b * S.nblk, S.nblk, S.seg, A, S.lds_keys, lkeys, gkeys,
-                                  reinterpret_cast<uint64_t *>(sbox), reinterpret_cast<int *>(smem + S.scr_off), P2, in_lds);
+  // more candidates than the LDS buffers hold: first only the head of the sorted list (top_keys; the box buffer is
+  // free until the boxes are decoded and lends it its histogram)
+  int n = gather_candidates(S.blk_count + (size_t)b * S.nblk, S.nblk, S.seg, A, S.lds_keys, lkeys, gkeys,
+                            reinterpret_cast<uint64_t *>(sbox), reinterpret_cast<int *>(smem + S.scr_off), P2, in_lds,
+                            reinterpret_cast<int *>(lbox), n_total);
   if (n == 0) {
     if (tid == 0) S.out_count[b] = 0;
     if (S.fin) finalize_epilogue(S, b, 0, nullptr, nullptr, reinterpret_cast<int *>(smem));
     return;
   }
+  bool head_only = n < n_total;
   NMS_STAMP(1);
-  if (tid < kNmsWindow) supp[tid] = 0;
-  if (tid == 0) *sK = 0;
-  __syncthreads();
+  // one pass over the candidates held in lkeys / gkeys (n, P2, in_lds): class-parallel or sorted sweep; returns K
+  auto attempt = [&](const int n, const int P2, const bool in_lds) -> int {
+    if (tid < kNmsWindow) supp[tid] = 0;
+    if (tid == 0) *sK = 0;
+    __syncthreads();
 
-  // ---- class-parallel suppression on the UNSORTED candidates (see class_parallel_nms): per-class NMS, few classes,
-  //      every candidate inside the max_nms cut, the candidates in the lower half of the LDS key buffer (the upper
-  //      half takes the grouped copy) and room for the scratch behind the grouped boxes -------------------------------
-  const int ncp = (S.nc + 1) & ~1;
-  const bool cp_try = in_lds && !S.agnostic && S.nc <= kCpMaxClasses && P2 <= 2 * kSortThreads && n <= S.max_nms &&
-                      2 * P2 <= S.lds_keys && (size_t)(S.lds_keys - P2) * sizeof(float4) >= cp_bytes(P2, ncp);
-  int K = 0;
-  bool done = false;
-  if (cp_try) {
-    const CpScratch CP = cp_carve(reinterpret_cast<unsigned char *>(lbox + P2), P2, ncp);
-    done = class_parallel_nms(CP, lkeys, lkeys + P2, lbox, pb, S.cls_of + (size_t)b * A, A, n, P2, ncp, S.max_det, S.max_wh, S.iou_thr, sK);
-    if (done) {
-      K = *sK;
-      for (int t = tid; t < K; t += kSortThreads) kpos[t] = t;   // the kept keys lie sorted at the head of the list
+    // ---- class-parallel suppression on the UNSORTED candidates (see class_parallel_nms): per-class NMS, few classes,
+    //      every candidate inside the max_nms cut, the candidates in the lower half of the LDS key buffer (the upper
+    //      half takes the grouped copy) and room for the scratch behind the grouped boxes -------------------------------
+    const int ncp = (S.nc + 1) & ~1;
+    const bool cp_try = in_lds && !S.agnostic && S.nc <= kCpMaxClasses && P2 <= 2 * kSortThreads && n <= S.max_nms &&
+                        2 * P2 <= S.lds_keys && (size_t)(S.lds_keys - P2) * sizeof(float4) >= cp_bytes(P2, ncp);
+    int K = 0;
+    bool done = false;
+    if (cp_try) {
+      const CpScratch CP = cp_carve(reinterpret_cast<unsigned char *>(lbox + P2), P2, ncp);
+      done = class_parallel_nms(CP, lkeys, lkeys + P2, lbox, pb, S.cls_of + (size_t)b * A, A, n, P2, ncp, S.max_det, S.max_wh, S.iou_thr, sK);
+      if (done) {
+        K = *sK;
+        for (int t = tid; t < K; t += kSortThreads) kpos[t] = t;   // the kept keys lie sorted at the head of the list
+        __syncthreads();
+      }
+    }
+
+    NMS_STAMP(2);
+    // ---- otherwise: sort the whole list, decode the sorted candidates' (class-offset) boxes ----------------------------
+    const int n_eff = min(n, S.max_nms);
+    if (!done) {
+      if (in_lds) bitonic_desc_lds(lkeys, P2);
+      else bitonic_desc(gkeys, P2);
+      NMS_STAMP(3);
+      for (int i = tid; i < n_eff; i += kSortThreads) {
+        const uint64_t key = in_lds ? lkeys[i] : gkeys[i];
+        const uint32_t anchor = ~(uint32_t)key;
+        const float cx = ldf(pb, anchor), cy = ldf(pb, (size_t)A + anchor), w = ldf(pb, (size_t)2 * A + anchor), h = ldf(pb, (size_t)3 * A + anchor);
+        const float hw = w / 2.0f, hh = h / 2.0f;
+        const float c = S.agnostic ? 0.0f : (float)S.cls_of[(size_t)b * A + anchor] * S.max_wh;
+        const float4 bx = make_float4((cx - hw) + c, (cy - hh) + c, (cx + hw) + c, (cy + hh) + c);
+        if (in_lds) lbox[i] = bx; else sbox[i] = bx;
+      }
       __syncthreads();
     }
-  }
 
-  NMS_STAMP(2);
-  // ---- otherwise: sort the whole list, decode the sorted candidates' (class-offset) boxes ----------------------------
-  const int n_eff = min(n, S.max_nms);
-  if (!done) {
-    if (in_lds) bitonic_desc_lds(lkeys, P2);
-    else bitonic_desc(gkeys, P2);
-    NMS_STAMP(3);
-    for (int i = tid; i < n_eff; i += kSortThreads) {
-      const uint64_t key = in_lds ? lkeys[i] : gkeys[i];
-      const uint32_t anchor = ~(uint32_t)key;
-      const float cx = ldf(pb, anchor), cy = ldf(pb, (size_t)A + anchor), w = ldf(pb, (size_t)2 * A + anchor), h = ldf(pb, (size_t)3 * A + anchor);
-      const float hw = w / 2.0f, hh = h / 2.0f;
-      const float c = S.agnostic ? 0.0f : (float)S.cls_of[(size_t)b * A + anchor] * S.max_wh;
-      const float4 bx = make_float4((cx - hw) + c, (cy - hh) + c, (cx + hw) + c, (cy + hh) + c);
-      if (in_lds) lbox[i] = bx; else sbox[i] = bx;
-    }
-    __syncthreads();
-  }
-
-  // ---- greedy NMS over the sorted list (agnostic NMS, many classes, few but large classes, boxes wider than the
-  //      class offset, or more candidates than the LDS buffers hold).  Every step looks at a WINDOW of the next 256
-  //      candidates: (A) all of them are tested against the boxes kept so far -- whoever is hit is dead for good,
-  //      kept boxes are final --, then the first 64 candidates still alive are compacted into one wave's lanes and
-  //      (B) resolved among themselves exactly (pair masks + fixpoint).  The step consumes the window up to the 65th
-  //      alive candidate (the whole window when at most 64 are alive).  In a dense scene nine candidates in ten die
-  //      in (A) once the first boxes are kept, so the serial steps (each a chain of LDS round trips and three
-  //      barriers) shrink from one per 64 candidates to one per 64 SURVIVORS of (A): 1152 candidates, agnostic:
-  //      18 -> 7 steps. ----------------------------------------------------------------------------------------------
-  NMS_STAMP(4);
-  for (int base = 0; !done && base < n_eff && K < S.max_det;) {
-    const int wn = min(kNmsWindow, n_eff - base);
-    // A: every lane holds four candidates of the window (one per 64-candidate sub-chunk) and every wave walks every
-    // sixteenth kept box, two per iteration so that the LDS broadcasts are issued together: a kept box read from
-    // LDS serves four pair tests.  Most kept boxes cannot meet any candidate (another class -- the class offset
-    // moves it 7680 px away -- or another place): a kept box whose x-extent meets no lane's (xx2 > xx1 is necessary
-    // for inter > 0, exactly) is dropped by one wave-uniform branch before the areas and the division are touched.
-    {
-      float4 wb[4];
-      float wa[4];
-      bool hit[4] = {false, false, false, false};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int wp = 64 * q + lane;
-        wb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (wp < wn) wb[q] = in_lds ? lbox[base + wp] : sbox[base + wp];
-        wa[q] = (wb[q].z - wb[q].x) * (wb[q].w - wb[q].y);
-      }
-      constexpr int NW = kSortThreads / 64;
-      int k = wave;
-      for (; k + NW < K; k += 2 * NW) {
-        const float a0 = kx1[k], e0 = kx2[k], c0 = ky1[k], f0 = ky2[k], r0 = karea[k];
-        const float a1 = kx1[k + NW], e1 = kx2[k + NW], c1 = ky1[k + NW], f1 = ky2[k + NW], r1 = karea[k + NW];
-        bool o0 = false, o1 = false;
-#pragma unroll
+    // ---- greedy NMS over the sorted list (agnostic NMS, many classes, few but large classes, boxes wider than the
+    //      class offset, or more candidates than the LDS buffers hold).  Every step looks at a WINDOW of the next 256
+    //      candidates: (A) all of them are tested against the boxes kept so far -- whoever is hit is dead for good,
+    //      kept boxes are final --, then the first 64 candidates still alive are compacted into one wave's lanes and
+    //      (B) resolved among themselves exactly (pair masks + fixpoint).  The step consumes the window up to the 65th
+    //      alive candidate (the whole window when at most 64 are alive).  In a dense scene nine candidates in ten die
+    //      in (A) once the first boxes are kept, so the serial steps (each a chain of LDS round trips and three
+    //      barriers) shrink from one per 64 candidates to one per 64 SURVIVORS of (A): 1152 candidates, agnostic:
+    //      18 -> 7 steps. ----------------------------------------------------------------------------------------------
+    NMS_STAMP(4);
+    for (int base = 0; !done && base < n_eff && K < S.max_det;) {
+      const int wn = min(kNmsWindow, n_eff - base);
+      // A: every lane holds four candidates of the window (one per 64-candidate sub-chunk) and every wave walks every
+      // sixteenth kept box, two per iteration so that the LDS broadcasts are issued together: a kept box read from
+      // LDS serves four pair tests.  Most kept boxes cannot meet any candidate (another class -- the class offset
+      // moves it 7680 px away -- or another place): a kept box whose x-extent meets no lane's (xx2 > xx1 is necessary
+      // for inter > 0, exactly) is dropped by one wave-uniform branch before the areas and the division are touched.
+      {
+        float4 wb[4];
+        float wa[4];
+        bool hit[4] = {false, false, false, false};
+  #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          o0 = o0 | (fminf(e0, wb[q].z) > fmaxf(a0, wb[q].x));
-          o1 = o1 | (fminf(e1, wb[q].z) > fmaxf(a1, wb[q].x));
+          const int wp = 64 * q + lane;
+          wb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (wp < wn) wb[q] = in_lds ? lbox[base + wp] : sbox[base + wp];
+          wa[q] = (wb[q].z - wb[q].x) * (wb[q].w - wb[q].y);
         }
-        if (__ballot(o0) != 0ull) {
-#pragma unroll
+        constexpr int NW = kSortThreads / 64;
+        int k = wave;
+        for (; k + NW < K; k += 2 * NW) {
+          const float a0 = kx1[k], e0 = kx2[k], c0 = ky1[k], f0 = ky2[k], r0 = karea[k];
+          const float a1 = kx1[k + NW], e1 = kx2[k + NW], c1 = ky1[k + NW], f1 = ky2[k + NW], r1 = karea[k + NW];
+          bool o0 = false, o1 = false;
+  #pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            o0 = o0 | (fminf(e0, wb[q].z) > fmaxf(a0, wb[q].x));
+            o1 = o1 | (fminf(e1, wb[q].z) > fmaxf(a1, wb[q].x));
+          }
+          if (__ballot(o0) != 0ull) {
+  #pragma unroll
+            for (int q = 0; q < 4; ++q) hit[q] = hit[q] | iou_gt(a0, c0, e0, f0, r0, wb[q].x, wb[q].y, wb[q].z, wb[q].w, wa[q], S.iou_thr);
+          }
+          if (__ballot(o1) != 0ull) {
+  #pragma unroll
+            for (int q = 0; q < 4; ++q) hit[q] = hit[q] | iou_gt(a1, c1, e1, f1, r1, wb[q].x, wb[q].y, wb[q].z, wb[q].w, wa[q], S.iou_thr);
+          }
+        }
+        if (k < K) {
+          const float a0 = kx1[k], e0 = kx2[k], c0 = ky1[k], f0 = ky2[k], r0 = karea[k];
+  #pragma unroll
           for (int q = 0; q < 4; ++q) hit[q] = hit[q] | iou_gt(a0, c0, e0, f0, r0, wb[q].x, wb[q].y, wb[q].z, wb[q].w, wa[q], S.iou_thr);
         }
-        if (__ballot(o1) != 0ull) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) hit[q] = hit[q] | iou_gt(a1, c1, e1, f1, r1, wb[q].x, wb[q].y, wb[q].z, wb[q].w, wa[q], S.iou_thr);
+  #pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (hit[q] && 64 * q + lane < wn) supp[64 * q + lane] = 1;
+      }
+      __syncthreads();
+
+      // the window's candidates still alive, as four 64-bit sets (every wave forms the same sets: no LDS round trip);
+      // lane t takes the t-th of them
+      uint64_t am[4];
+      int ac[4];
+  #pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        am[q] = __ballot(64 * q + lane < wn && supp[64 * q + lane] == 0);
+        ac[q] = __builtin_popcountll(am[q]);
+      }
+      const int alive_n = ac[0] + ac[1] + ac[2] + ac[3];
+      const int m = min(64, alive_n);
+      int mypos = 0;
+      float4 cb = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane < m) {
+        mypos = nth_alive(am, ac, lane);
+        cb = in_lds ? lbox[base + mypos] : sbox[base + mypos];
+      }
+      const float carea = (cb.z - cb.x) * (cb.w - cb.y);
+
+      // B: pair masks among the (up to) 64 alive candidates, by column: pairmask[j] = lanes i < j whose box would
+      // suppress j's (same x-extent shortcut)
+  #pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = __builtin_amdgcn_readfirstlane(wave) * 4 + q;  // wave-uniform: the box of lane j comes by readlane
+        const float bx1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb.x), j));
+        const float bx2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb.z), j));
+        uint64_t mask = 0ull;
+        if (__ballot((lane < j) && fminf(cb.z, bx2) > fmaxf(cb.x, bx1)) != 0ull) {
+          const float by1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb.y), j));
+          const float by2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb.w), j));
+          const float barea = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(carea), j));
+          const bool p = (lane < j) && (j < m) && iou_gt(cb.x, cb.y, cb.z, cb.w, carea, bx1, by1, bx2, by2, barea, S.iou_thr);
+          mask = __ballot(p);
         }
+        if (lane == 0) pairmask[j] = mask;
       }
-      if (k < K) {
-        const float a0 = kx1[k], e0 = kx2[k], c0 = ky1[k], f0 = ky2[k], r0 = karea[k];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) hit[q] = hit[q] | iou_gt(a0, c0, e0, f0, r0, wb[q].x, wb[q].y, wb[q].z, wb[q].w, wa[q], S.iou_thr);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (hit[q] && 64 * q + lane < wn) supp[64 * q + lane] = 1;
-    }
-    __syncthreads();
+      __syncthreads();
 
-    // the window's candidates still alive, as four 64-bit sets (every wave forms the same sets: no LDS round trip);
-    // lane t takes the t-th of them
-    uint64_t am[4];
-    int ac[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      am[q] = __ballot(64 * q + lane < wn && supp[64 * q + lane] == 0);
-      ac[q] = __builtin_popcountll(am[q]);
+      if (wave == 0) {
+        // Greedy suppression among them as a fixpoint: S = candidates kept so far; lane j stays iff no kept i < j
+        // suppresses it.  After t rounds the first t lanes are final (by induction on j), so the loop ends within 64
+        // rounds and a round that changes nothing has reached the greedy answer -- in practice after the length of the
+        // longest suppression chain, 2-5 rounds, instead of one serial step per kept box.
+        const uint64_t alive = __ballot(lane < m);
+        const uint64_t col = pairmask[lane];
+        uint64_t keep_set = alive;
+        for (int round = 0; round < 65; ++round) {   // 64 rounds settle every lane; the bound is belt and braces
+          const uint64_t next = alive & ~__ballot((col & keep_set) != 0ull);
+          if (next == keep_set) break;
+          keep_set = next;
+        }
+        // at most max_det rows in all: the first (max_det - K) kept lanes of this step
+        const int rank = __builtin_popcountll(keep_set & ((1ull << lane) - 1ull));
+        const uint64_t keepm = __ballot(((keep_set >> lane) & 1ull) && K + rank < S.max_det);
+        const int Kl = K + __builtin_popcountll(keepm);
+        if ((keepm >> lane) & 1ull) {
+          const int idx = K + __builtin_popcountll(keepm & ((1ull << lane) - 1ull));
+          kx1[idx] = cb.x; ky1[idx] = cb.y; kx2[idx] = cb.z; ky2[idx] = cb.w;
+          karea[idx] = carea;
+          kpos[idx] = base + mypos;
+        }
+  #pragma unroll
+        for (int q = 0; q < 4; ++q) supp[64 * q + lane] = 0;   // every wave read its flags before the barrier above
+        // the step consumes the window up to the 65th alive candidate (>= 64 positions), all of it when at most 64
+        // are alive (>= 1): found by wave 0 alone, the other waves read it with K
+        const int used = alive_n > 64 ? nth_alive(am, ac, 64) : wn;
+        if (lane == 0) { sK[0] = Kl; sK[1] = used; }
+      }
+      __syncthreads();
+      K = sK[0];
+      base += sK[1];
     }
-    const int alive_n = ac[0] + ac[1] + ac[2] + ac[3];
-    const int m = min(64, alive_n);
-    int mypos = 0;
-    float4 cb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < m) {
-      mypos = nth_alive(am, ac, lane);
-      cb = in_lds ? lbox[base + mypos] : sbox[base + mypos];
-    }
-    const float carea = (cb.z - cb.x) * (cb.w - cb.y);
 
-    // B: pair masks among the (up to) 64 alive candidates, by column: pairmask[j] = lanes i < j whose box would
-    // suppress j's (same x-extent shortcut)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int j = __builtin_amdgcn_readfirstlane(wave) * 4 + q;  // wave-uniform: the box of lane j comes by readlane
-      const float bx1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb.x), j));
-      const float bx2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb.z), j));
-      uint64_t mask = 0ull;
-      if (__ballot((lane < j) && fminf(cb.z, bx2) > fmaxf(cb.x, bx1)) != 0ull) {
-        const float by1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb.y), j));
-        const float by2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb.w), j));
-        const float barea = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(carea), j));
-        const bool p = (lane < j) && (j < m) && iou_gt(cb.x, cb.y, cb.z, cb.w, carea, bx1, by1, bx2, by2, barea, S.iou_thr);
-        mask = __ballot(p);
-      }
-      if (lane == 0) pairmask[j] = mask;
-    }
+    NMS_STAMP(5);
+    return K;
+  };
+  int K = attempt(n, P2, in_lds);
+  // the head of the list ended short of max_det keeps although candidates remain: the whole list after all (sorted in
+  // global memory).  Uniform: every lane sees the same K and counts.
+  if (head_only && K < S.max_det && n < min(n_total, S.max_nms)) {
+    head_only = false;
     __syncthreads();
-
-    if (wave == 0) {
-      // Greedy suppression among them as a fixpoint: S = candidates kept so far; lane j stays iff no kept i < j
-      // suppresses it.  After t rounds the first t lanes are final (by induction on j), so the loop ends within 64
-      // rounds and a round that changes nothing has reached the greedy answer -- in practice after the length of the
-      // longest suppression chain, 2-5 rounds, instead of one serial step per kept box.
-      const uint64_t alive = __ballot(lane < m);
-      const uint64_t col = pairmask[lane];
-      uint64_t keep_set = alive;
-      for (int round = 0; round < 65; ++round) {   // 64 rounds settle every lane; the bound is belt and braces
-        const uint64_t next = alive & ~__ballot((col & keep_set) != 0ull);
-        if (next == keep_set) break;
-        keep_set = next;
-      }
-      // at most max_det rows in all: the first (max_det - K) kept lanes of this step
-      const int rank = __builtin_popcountll(keep_set & ((1ull << lane) - 1ull));
-      const uint64_t keepm = __ballot(((keep_set >> lane) & 1ull) && K + rank < S.max_det);
-      const int Kl = K + __builtin_popcountll(keepm);
-      if ((keepm >> lane) & 1ull) {
-        const int idx = K + __builtin_popcountll(keepm & ((1ull << lane) - 1ull));
-        kx1[idx] = cb.x; ky1[idx] = cb.y; kx2[idx] = cb.z; ky2[idx] = cb.w;
-        karea[idx] = carea;
-        kpos[idx] = base + mypos;
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) supp[64 * q + lane] = 0;   // every wave read its flags before the barrier above
-      // the step consumes the window up to the 65th alive candidate (>= 64 positions), all of it when at most 64
-      // are alive (>= 1): found by wave 0 alone, the other waves read it with K
-      const int used = alive_n > 64 ? nth_alive(am, ac, 64) : wn;
-      if (lane == 0) { sK[0] = Kl; sK[1] = used; }
-    }
-    __syncthreads();
-    K = sK[0];
-    base += sK[1];
+    n = gather_candidates(S.blk_count + (size_t)b * S.nblk, S.nblk, S.seg, A, S.lds_keys, lkeys, gkeys,
+                          reinterpret_cast<uint64_t *>(sbox), reinterpret_cast<int *>(smem + S.scr_off), P2, in_lds, nullptr, n_total);
+    K = attempt(n, P2, in_lds);
   }
 
-  NMS_STAMP(5);
   // ---- emit rows: x1,y1,x2,y2 (no class offset), conf, cls, coef... ---------------------------------
   if (tid == 0) S.out_count[b] = K;
   const int row = 6 + S.nm;
@@ -1028,8 +1143,10 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_rotated(SortNmsParams S
 
   int P2 = 0;
   bool in_lds = true;
+  int n_total = 0;   // the rotated suppression is not a greedy pass that stops early: it always takes the whole list
   const int n = gather_candidates(S.blk_count + (size_t)b * S.nblk, S.nblk, S.seg, A, S.lds_keys, lkeys, gkeys,
-                                  reinterpret_cast<uint64_t *>(S.sbox + (size_t)b * A), reinterpret_cast<int *>(smem + S.scr_off), P2, in_lds);
+                                  reinterpret_cast<uint64_t *>(S.sbox + (size_t)b * A), reinterpret_cast<int *>(smem + S.scr_off), P2, in_lds,
+                                  nullptr, n_total);
   if (n == 0) {
     if (tid == 0) S.out_count[b] = 0;
     return;

@@ -356,3 +356,42 @@ def test_nms_sorted_sweep_windows(ops, seed):
             tag = f"nc={nc} objects={objects} agnostic={agn} max_det={md} image {b}"
             assert anchor[b, :n].cpu().numpy().tolist() == ra.tolist(), tag
             assert n == 0 or np.array_equal(det[b, :n].cpu().numpy(), rd.astype(F32)), tag
+
+
+@pytest.mark.parametrize("seed", sweep_seeds(4097))
+def test_nms_more_candidates_than_the_lds_buffers_hold(ops, seed):
+    """Validation-style thresholds: (nearly) every one of 8400 anchors is a candidate.  The kernel first takes only the
+    head of the sorted list (the 4096 largest keys, by a radix histogram) and comes back for the whole list when that
+    ends short of max_det keeps: random boxes (max_det keeps come from the head), boxes in a few tight clusters (far
+    fewer keeps than max_det: the whole list), many equal scores at the cut, a tiny max_det, agnostic and per class."""
+    rng = np.random.default_rng(seed)
+    A = 8400
+
+    def head(nc, clusters, quant):
+        p = np.zeros((2, 4 + nc, A), F32)
+        if clusters:
+            ctr = rng.uniform(60, 580, (clusters, 2)); wh = rng.uniform(30, 120, (clusters, 2))
+            k = rng.integers(0, clusters, (2, A))
+            p[:, 0:2] = np.moveaxis(ctr[k], -1, 1) + rng.normal(0, 0.7, (2, 2, A))
+            p[:, 2:4] = np.moveaxis(wh[k], -1, 1) * np.exp(rng.normal(0, 0.01, (2, 2, A)))
+        else:
+            p[:, 0:2] = rng.uniform(0, 640, (2, 2, A))
+            p[:, 2:4] = rng.uniform(10, 200, (2, 2, A))
+        sc = rng.uniform(0.011, 0.95, (2, nc, A)).astype(F32) * (rng.random((2, nc, A)) < 0.6)
+        if quant:
+            sc = np.round(sc * quant) / quant     # long runs of equal scores, also across the 4096-key cut
+        p[:, 4:] = sc
+        return p
+
+    for nc, clusters, quant, agn, md, iou in [(3, 0, 0, False, 300, 0.7), (3, 40, 0, False, 300, 0.45), (80, 25, 0, True, 300, 0.45),
+                                              (2, 0, 64, True, 300, 0.6), (1, 60, 16, False, 5, 0.45), (5, 0, 0, False, 1000, 0.3)]:
+        p = head(nc, clusters, quant)
+        assert (p[:, 4:].max(1) > 0.01).sum(1).min() > 4096
+        det, count, anchor = ops.nms_v8(dev(p), 0.01, iou, agnostic=agn, max_det=md, nc=nc)
+        torch.cuda.synchronize()
+        ref = ON.non_max_suppression(p, 0.01, iou, agnostic=agn, max_det=md, nc=nc)
+        for b, (rd, ra) in enumerate(ref):
+            n = int(count[b])
+            tag = f"nc={nc} clusters={clusters} quant={quant} agnostic={agn} max_det={md} image {b}"
+            assert anchor[b, :n].cpu().numpy().tolist() == ra.tolist(), tag
+            assert n == 0 or np.array_equal(det[b, :n].cpu().numpy(), rd.astype(F32)), tag
