@@ -346,3 +346,28 @@ def test_folder_harness_writes_the_reference_csv(models, tmp_path):
         b[:, [1, 3]] /= rh
         want += run_folder.result_rows(f"f{i:02d}.png", b, scores, classes, None)
     assert len(want) > 0 and rows == [[str(v) for v in r] for r in want]
+
+
+def test_letterbox_uploads_host_frames_through_pinned_staging(models):
+    """Host frames (numpy arrays, CPU tensors, a 4-D host batch, pinned tensors, mixed with device tensors) give the
+    tensor the device-resident frames give; the staging buffer is reused by the next call."""
+    m = models[0]
+    rng = np.random.default_rng(31)
+    sizes = [(270, 480), (375, 500), (270, 480), (1080, 1920), (64, 48), (720, 1280)]
+    frames = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    ref, ref_ops = m.letterbox([torch.from_numpy(f).cuda() for f in frames], (320, 320))
+    for trial in range(2):          # the second call reuses the staging buffer
+        got, ops_ = m.letterbox(frames, (320, 320))
+        assert torch.equal(got, ref) and ops_ == ref_ops
+    mixed = [frames[0], torch.from_numpy(frames[1]), torch.from_numpy(frames[2]).cuda(), torch.from_numpy(frames[3]).pin_memory(),
+             frames[4], torch.from_numpy(frames[5])]
+    got, _ = m.letterbox(mixed, (320, 320))
+    assert torch.equal(got, ref)
+    batch = rng.integers(0, 256, (9, 375, 500, 3), dtype=np.uint8)     # frames 562500 bytes apart: packed, read in place
+    ref4, _ = m.letterbox(torch.from_numpy(batch).cuda(), (320, 320))
+    got4, _ = m.letterbox(batch, (320, 320))
+    assert torch.equal(got4, ref4)
+    grey = rng.integers(0, 256, (4, 120, 200), dtype=np.uint8)
+    g_ref, _ = m.letterbox([torch.from_numpy(g).cuda() for g in grey], (160, 160))
+    g_got, _ = m.letterbox([g for g in grey], (160, 160))
+    assert torch.equal(g_got, g_ref)
