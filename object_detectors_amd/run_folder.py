@@ -2,8 +2,8 @@
 
 The file-in / file-out loop of the reference's runner `object_detectors/yolov8_lmi/run_model.py:72-183`
 (same arguments: -w -i -o --sz -c --csv --obb --pose), restricted to what belongs to the accelerated path: the
-frames of a batch are decoded on the host (PIL; the reference uses cv2.imread), uploaded once and resized on the
-GPU in one launch.  Drawing annotated images (cv2 text and line rendering, run_model.py:122-151,177) is
+frames of a batch are decoded on the host (PIL on worker threads, the next batch's while the GPU works on this
+one; the reference uses cv2.imread), uploaded once and resized on the GPU in one launch.  Drawing annotated images (cv2 text and line rendering, run_model.py:122-151,177) is
 visualisation and is not done here.
 
 Geometry.  `--geometry stretch` (the default) is the reference runner's own: every frame is STRETCHED to --sz with
@@ -138,9 +138,15 @@ def run(model, path_imgs: str, path_out: str, sz, confidence=0.25, save_csv=True
     rows, n_img, n_det = [], 0, 0
     t = collections.Counter()
     t_all = time.time()
-    for batch in batches:
+    # the files of a batch are decoded by worker threads (PIL releases the GIL while it decodes), and the next batch's
+    # while the GPU works on this one: 'decode' below is the time the loop still waits for frames
+    import concurrent.futures
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) // 2)), thread_name_prefix='lmi-decode')
+    pending = [pool.submit(load_rgb, p) for p in batches[0]] if batches else []
+    for bi, batch in enumerate(batches):
         t0 = time.time()
-        frames = [load_rgb(p) for p in batch]
+        frames = [f.result() for f in pending]
+        pending = [pool.submit(load_rgb, p) for p in batches[bi + 1]] if bi + 1 < len(batches) else []
         t['decode'] += time.time() - t0
         if geometry == 'stretch':
             results, ti = predict_stretched(model, frames, confidence, sz)
@@ -158,6 +164,7 @@ def run(model, path_imgs: str, path_out: str, sz, confidence=0.25, save_csv=True
             for c, k in collections.Counter(results['classes'][r]).items():
                 logger.info(f'{name}: found {k} {c}')
         n_img += len(batch)
+    pool.shutdown()
     wall = time.time() - t_all
     if save_csv:
         write_rows(rows, os.path.join(path_out, 'preds.csv'))
