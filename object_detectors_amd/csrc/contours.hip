@@ -197,8 +197,9 @@ int64_t lmi_trace_contours_host(const uint64_t *words, int64_t m, const int32_t 
       for (size_t k = begin; k < end; ++k) { r.push_back(c.xy[2 * k] + b[0]); r.push_back(c.xy[2 * k + 1] + b[1]); }
     }
   };
+  // a worker thread costs ~20 us to start and join, a mask ~40 us to trace: one thread per 8 masks, `threads` at most
   int nt = threads > 0 ? threads : 1;
-  if ((int64_t)nt > m) nt = (int)(m > 0 ? m : 1);
+  if ((int64_t)nt > (m + 7) / 8) nt = (int)((m + 7) / 8 > 0 ? (m + 7) / 8 : 1);
   std::vector<std::thread> pool;
   for (int t = 1; t < nt; ++t) pool.emplace_back(work);
   work();

@@ -348,8 +348,9 @@ class Yolov8Core:
                 results['masks'].append(masks if (return_tensor or masks_on_device) else self._d2h(masks))
                 if return_segments:   # bit-packed box regions are copied to the host, contours traced there in C++
                     segments = masks2segments(masks, boxes=det_h[i, :n, :4][M] if len(masks) == int(M.sum()) else None)
-                    if return_tensor:
-                        segments = [self.from_numpy(x) for x in segments]
+                    if return_tensor and len(segments):   # one upload for all contours of the image, per-mask results are views
+                        flat = self.from_numpy(np.concatenate(segments) if len(segments) > 1 else segments[0])
+                        segments = list(torch.split(flat, [len(x) for x in segments]))
                     results['segments'].append(segments)
             if return_tensor:
                 a, b = (int(slot_base[i]), int(slot_base[i + 1])) if rows_dev is not None else (0, 0)
