@@ -33,6 +33,7 @@ def _hip_ops():
 
 
 _POOL = None
+_POOL_WORKERS = max(1, min(8, (os.cpu_count() or 2) // 2))
 
 
 def _upload_pool():
@@ -40,7 +41,7 @@ def _upload_pool():
     global _POOL
     if _POOL is None:
         import concurrent.futures
-        _POOL = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) // 2)), thread_name_prefix="lmi-upload")
+        _POOL = concurrent.futures.ThreadPoolExecutor(max_workers=_POOL_WORKERS, thread_name_prefix="lmi-upload")
     return _POOL
 
 
@@ -148,7 +149,7 @@ class Yolov8Core:
             frames = torch.from_numpy(frames)
         if isinstance(frames, torch.Tensor):
             if frames.is_cuda or frames.ndim != 4 or frames.shape[0] < 2:
-                frames = frames.to(self.device, non_blocking=frames.is_cuda or frames.is_pinned())
+                frames = frames.to(self.device)
             else:   # a host batch (B,H,W,C): frame by frame through the staging buffer, one packed batch on the device
                 parts = self._upload_frames(list(frames.unbind(0)))
                 a, b = parts[0], parts[-1]
@@ -164,12 +165,14 @@ class Yolov8Core:
         host-to-device copies on the caller's stream, so the staging memcpy of one frame overlaps the PCIe transfer of
         another -- into ONE packed device buffer (the letterbox reads frames at any byte address): 64 x 1080p frames
         8.9 ms against 16 ms for a pageable `.to(device)` per frame (the link alone: 6.9 ms).  Device tensors and
-        pinned tensors are passed on as they are / copied asynchronously."""
+        the caller's own pinned tensors are passed on as they are / copied with a plain `.to(device)` (which returns
+        once the source may be reused)."""
         host = [i for i, f in enumerate(frames) if not f.is_cuda and not f.is_pinned() and f.dtype == torch.uint8 and f.numel() > 0]
+        staged = set(host)
         out = [None] * len(frames)
         for i, f in enumerate(frames):
-            if i not in host:
-                out[i] = f.to(self.device, non_blocking=True)
+            if i not in staged:
+                out[i] = f.to(self.device)
         if not host:
             return out
         srcs = [frames[i].contiguous() for i in host]
@@ -192,7 +195,7 @@ class Yolov8Core:
             with torch.inference_mode(), torch.cuda.stream(stream):  # both are per-thread states
                 dev[offs[k0]:offs[k1]].copy_(pin[offs[k0]:offs[k1]], non_blocking=True)
 
-        workers = _upload_pool()._max_workers if (len(srcs) > 1 and total >= (8 << 20)) else 1
+        workers = _POOL_WORKERS if (len(srcs) > 1 and total >= (8 << 20)) else 1
         if workers > 1:
             # contiguous runs of frames of about equal bytes, two per worker: a run's transfer overlaps the others' memcpy
             # (one task per frame costs ~100 us of stream / GIL hand-over each: slower than a pageable copy on small frames)
