@@ -332,6 +332,21 @@ constexpr size_t kGatherLds = sizeof(int) * (2 * kGatherChunk + 32);   // gather
 // sweeps them in LDS; only if that ends short of max_det keeps does it come back for the whole list (global-memory
 // sort, ~400 us).  hist: LDS, see kTopBins.  Returns the number of keys taken (0: the cut fell on a run of more
 // than `cap` keys with equal leading 24 score bits -- nothing copied, take the whole list).  All lanes call this.
+// number of candidates of an image (what gather_candidates finds first); all lanes call this
+__device__ int candidate_total(const int *__restrict__ cnt, int nblk, int A, int *scr) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int part = 0;
+  for (int i = tid; i < nblk; i += kSortThreads) part += cnt[i];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
+  if (lane == 0) scr[wave] = part;
+  __syncthreads();
+  int n = 0;
+  for (int w = 0; w < kSortThreads / 64; ++w) n += scr[w];
+  __syncthreads();
+  return min(n, A);
+}
+
 constexpr int kTopBins = 4096;   // hist: kTopBins + 4 + kSortThreads / 64 ints
 
 // smallest bin c with (keys in bins >= c) <= budget; res[0] = c (kTopBins: not even the last bin fits), res[1] = that count
@@ -777,6 +792,7 @@ struct SortNmsParams {
   int lds_keys;  // capacity (keys) of the LDS sort buffer
   int lbox_off;  // byte offset of the LDS box buffer (lds_keys float4)
   float2 *scd;   // rotated: covariance c and reach per sorted candidate (global copy)
+  int rot_groups; // rotated: workgroups per image that share the pair tests (1: one workgroup does everything)
 };
 
 // Fused per-image half of `lmi_finalize_detections` (finalize_boxes_kernel is the stand-alone form): the per-class
@@ -1135,11 +1151,25 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_rotated(SortNmsParams S
   float4 *lbox = reinterpret_cast<float4 *>(smem + S.lbox_off);   // x + off, y + off, a, b
   float2 *lcd = reinterpret_cast<float2 *>(lbox + S.lds_keys);     // c, reach
 
-  const int b = blockIdx.x;
+  // G workgroups per image (host: as many as leave every workgroup a CU of its own).  The pair tests are independent
+  // per column, unlike the greedy pass, so they can be shared out -- but one workgroup runs on ONE CU, and a dense
+  // scene (300 large boxes of one class: 1.1 ms) is bound by its vector ALU.  Every workgroup of an image gathers,
+  // sorts and decodes the SAME list in its own LDS (redundant, but on CUs that would idle, and without a
+  // synchronisation between workgroups), tests only its own columns (wave w of group g: columns w + 16 g mod 16 G),
+  // and leaves their keep flags -- group 0 also the sorted keys -- in the image's global scratch; nms_rotated_emit
+  // (a second launch) compacts and writes the rows.  Images with more candidates than the LDS buffers hold are done by
+  // group 0 alone, start to finish, as with G = 1.
+  const int G = S.rot_groups > 1 ? S.rot_groups : 1;
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int A = S.A, C = 4 + S.nc + S.nm;
   const InT *pb = reinterpret_cast<const InT *>(S.pred) + (size_t)b * C * A;
   uint64_t *gkeys = S.keys + (size_t)b * S.P;
+  int *gn = reinterpret_cast<int *>(S.scd + (size_t)b * A);   // split images: n_eff for nms_rotated_emit; -1: rows written here
+  if (g > 0) {
+    const int nn = candidate_total(S.blk_count + (size_t)b * S.nblk, S.nblk, A, reinterpret_cast<int *>(smem + S.scr_off));
+    if (nn == 0 || next_pow2(nn) > S.lds_keys) return;   // nothing to do / group 0 takes the whole image (global-memory path)
+  }
 
   int P2 = 0;
   bool in_lds = true;
@@ -1148,9 +1178,10 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_rotated(SortNmsParams S
                                   reinterpret_cast<uint64_t *>(S.sbox + (size_t)b * A), reinterpret_cast<int *>(smem + S.scr_off), P2, in_lds,
                                   nullptr, n_total);
   if (n == 0) {
-    if (tid == 0) S.out_count[b] = 0;
+    if (tid == 0) { S.out_count[b] = 0; if (G > 1) *gn = -1; }
     return;
   }
+  const bool split = G > 1 && in_lds;
   if (in_lds) bitonic_desc_lds(lkeys, P2);
   else bitonic_desc(gkeys, P2);
   uint64_t *keys = in_lds ? lkeys : gkeys;
@@ -1206,7 +1237,8 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_rotated(SortNmsParams S
         if (!(v < S.iou_thr)) atomicAnd(key_lo + 2 * j, 0x7fffffffu);
       }
     };
-    for (int j = wave; j < n_eff; j += kSortThreads / 64) {
+    const int jstep = (kSortThreads / 64) * (split ? G : 1);
+    for (int j = wave + (split ? (kSortThreads / 64) * g : 0); j < n_eff; j += jstep) {
       if (!(key_lo[2 * j] >> 31)) continue;   // dropped already by a pair evaluated earlier (a drop is final)
       const float4 bj = box[j];
       const float rj = cd[j].y;
@@ -1237,7 +1269,21 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_rotated(SortNmsParams S
     __builtin_amdgcn_wave_barrier();
     evaluate(qn);
   }
-  if (tid == 0) wcnt[16] = 0;
+  if (split) {
+    // the keep flags of this group's columns and (group 0) the sorted keys, for nms_rotated_emit
+    __syncthreads();
+    unsigned char *gflags = reinterpret_cast<unsigned char *>(S.sbox + (size_t)b * A);   // n_eff bytes, then the keys
+    constexpr int NW = kSortThreads / 64;
+    for (int j = NW * g + (tid % NW) + NW * G * (tid / NW); j < n_eff; j += NW * G * (kSortThreads / NW))
+      gflags[j] = (unsigned char)((keys[j] >> 31) & 1ull);
+    if (g == 0) {
+      uint64_t *gsorted = reinterpret_cast<uint64_t *>(gflags + ((n_eff + 15) & ~15));
+      for (int j = tid; j < n_eff; j += kSortThreads) gsorted[j] = keys[j];
+      if (tid == 0) *gn = n_eff;
+    }
+    return;
+  }
+  if (tid == 0) { wcnt[16] = 0; if (G > 1) *gn = -1; }
   __syncthreads();
 
   // ordered compaction of the survivors, first max_det of them
@@ -1263,6 +1309,61 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_rotated(SortNmsParams S
   }
   const int K = wcnt[16];
 
+  if (tid == 0) S.out_count[b] = K;
+  const int row = 6 + S.nm;
+  float *od = S.out_det + (size_t)b * S.max_det * row;
+  for (int e = tid; e < K * row; e += kSortThreads) {
+    const int t = e / row, col = e - t * row;
+    const uint64_t key = keys[kpos[t]];
+    const uint32_t anchor = ~(uint32_t)key & 0x7fffffffu;
+    float v;
+    if (col < 4) v = ldf(pb, (size_t)col * A + anchor);
+    else if (col == 4) v = sortable2f((uint32_t)(key >> 32));
+    else if (col == 5) v = (float)S.cls_of[(size_t)b * A + anchor];
+    else v = ldf(pb, (size_t)(4 + S.nc + (col - 6)) * A + anchor);
+    od[e] = v;
+    if (col == 0) S.out_anchor[(size_t)b * S.max_det + t] = (int)anchor;
+  }
+}
+
+// Second launch of the split rotated NMS (rot_groups > 1): one workgroup per image compacts the survivors in score
+// order from the keep flags the groups left, and writes the rows -- the tail of nms_sort_rotated on the global copies.
+template <typename InT>
+__global__ __launch_bounds__(kSortThreads) void nms_rotated_emit(SortNmsParams S) {
+  __shared__ int kpos[LMI_MAX_DET_CAP];
+  __shared__ int wcnt[kSortThreads / 64 + 1];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int A = S.A, C = 4 + S.nc + S.nm;
+  const int n_eff = *reinterpret_cast<const int *>(S.scd + (size_t)b * A);
+  if (n_eff <= 0) return;   // -1: nms_sort_rotated wrote this image's rows itself
+  const InT *pb = reinterpret_cast<const InT *>(S.pred) + (size_t)b * C * A;
+  const unsigned char *flags = reinterpret_cast<const unsigned char *>(S.sbox + (size_t)b * A);
+  const uint64_t *keys = reinterpret_cast<const uint64_t *>(flags + ((n_eff + 15) & ~15));
+  constexpr int NW = kSortThreads / 64;
+  if (tid == 0) wcnt[NW] = 0;
+  __syncthreads();
+  for (int base = 0; base < n_eff; base += kSortThreads) {
+    const int K = wcnt[NW];
+    if (K >= S.max_det) break;
+    const int j = base + tid;
+    const bool k = j < n_eff && flags[j] != 0;
+    const uint64_t m = __ballot(k);
+    if (lane == 0) wcnt[wave] = __builtin_popcountll(m);
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < NW; ++w) {
+      const int t = wcnt[w];
+      if (w < wave) before += t;
+      total += t;
+    }
+    const int idx = K + before + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (k && idx < S.max_det) kpos[idx] = j;
+    __syncthreads();
+    if (tid == 0) wcnt[NW] = min(K + total, S.max_det);
+    __syncthreads();
+  }
+  const int K = wcnt[NW];
   if (tid == 0) S.out_count[b] = K;
   const int row = 6 + S.nm;
   float *od = S.out_det + (size_t)b * S.max_det * row;
@@ -1457,6 +1558,7 @@ constexpr int kMaxDevices = 64;
 struct NmsDeviceState {
   bool ready = false;
   void *scratch_ptr = nullptr;
+  int cu_count = 0;
 };
 static std::mutex g_nms_dev_mutex;
 static NmsDeviceState g_nms_dev[kMaxDevices];
@@ -1492,6 +1594,9 @@ static int nms_device_state(NmsDeviceState **out) {
     e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
     if (e != hipSuccess || ptr == nullptr) { lmi_set_error("lmi_nms: hipGetSymbolAddress(scratch): %s", hipGetErrorString(e)); return LMI_ERR_LAUNCH; }
     D.scratch_ptr = ptr;
+    int cus = 0;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    D.cu_count = (e == hipSuccess && cus > 0) ? cus : 1;
     D.ready = true;
   }
   *out = &D;
@@ -1606,9 +1711,19 @@ static int nms_suppress(const NmsCall &C, const void *pred, int batch, int nc, i
     S.lbox_off = (int)((nms_lds_rot_head(S.lds_keys, max_det) + 15) & ~(size_t)15);
     S.scr_off = (int)((size_t)S.lbox_off + (size_t)S.lds_keys * (16 + 8));
     const size_t lds_rot = (size_t)S.scr_off + kGatherLds + kRotQueueLds;
-    if (C.half) hipLaunchKernelGGL(nms_sort_rotated<__half>, dim3(batch), dim3(kSortThreads), lds_rot, C.s, S);
-    else hipLaunchKernelGGL(nms_sort_rotated<float>, dim3(batch), dim3(kSortThreads), lds_rot, C.s, S);
-    return lmi_check_launch("nms_sort_rotated");
+    // workgroups per image: as many as leave every workgroup of the launch a CU of its own (they are 1024 lanes and
+    // ~150 KiB of LDS each), 16 at most; the per-image scratch of the split needs 9 bytes per candidate
+    int G = D->cu_count / batch;
+    if (G > 16) G = 16;
+    if (G < 2 || anchors < 16) G = 1;
+    S.rot_groups = G;
+    if (C.half) hipLaunchKernelGGL(nms_sort_rotated<__half>, dim3(batch * G), dim3(kSortThreads), lds_rot, C.s, S);
+    else hipLaunchKernelGGL(nms_sort_rotated<float>, dim3(batch * G), dim3(kSortThreads), lds_rot, C.s, S);
+    int rcr = lmi_check_launch("nms_sort_rotated");
+    if (rcr || G == 1) return rcr;
+    if (C.half) hipLaunchKernelGGL(nms_rotated_emit<__half>, dim3(batch), dim3(kSortThreads), 0, C.s, S);
+    else hipLaunchKernelGGL(nms_rotated_emit<float>, dim3(batch), dim3(kSortThreads), 0, C.s, S);
+    return lmi_check_launch("nms_rotated_emit");
   }
   S.lbox_off = (int)((nms_lds_small(S.lds_keys, max_det) + 15) & ~(size_t)15);
   S.scr_off = (int)((size_t)S.lbox_off + (size_t)S.lds_keys * 16);
