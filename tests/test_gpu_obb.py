@@ -171,3 +171,27 @@ def test_rotated_nms_far_pair_shortcut_is_exact(seed, agnostic):
     assert margin > 2e-5, "seed puts a decision on the threshold: pick another"
     n = int(count[0])
     assert 10 < n < A and anchor[0, :n].cpu().tolist() == ra.tolist()
+
+
+def test_rotated_nms_any_number_of_workgroups_per_image():
+    """The pair tests of an image are shared by as many workgroups as the batch leaves CUs for (16 for one image, one
+    from 129 images on): every batch size gives each image the rows it gets when it is suppressed alone, also when the
+    images of a batch differ in their candidate counts (one with none, one above the LDS buffers)."""
+    from object_detectors_amd import hip_ops as ops
+    rng = np.random.default_rng(21)
+    nc = 4
+    p = obb_head(rng, 12, nc, 320, 30)
+    p[3, 4:4 + nc] = 0.0                      # an image without candidates
+    big = torch.from_numpy(np.concatenate([p] * 11)[:130]).cuda()      # 130 images: one workgroup per image
+    ref_rows = {}
+    for b in range(12):                        # alone: 16 workgroups for the image
+        d, c, a = ops.nms_v8(big[b:b + 1].contiguous(), 0.25, 0.3, nc=nc, rotated=True)
+        ref_rows[b] = (int(c[0]), a[0, :int(c[0])].cpu().numpy().tolist(), d[0, :int(c[0])].cpu().numpy())
+    assert ref_rows[3][0] == 0 and max(v[0] for v in ref_rows.values()) > 5
+    for B in (130, 64, 24, 7, 2):
+        d, c, a = ops.nms_v8(big[:B].contiguous(), 0.25, 0.3, nc=nc, rotated=True)
+        torch.cuda.synchronize()
+        for b in range(B):
+            n, anchors, rows = ref_rows[b % 12]
+            assert int(c[b]) == n and a[b, :n].cpu().numpy().tolist() == anchors, (B, b)
+            assert np.array_equal(d[b, :n].cpu().numpy(), rows), (B, b)
