@@ -50,6 +50,7 @@ WORKLOADS = {
                          desc="YOLOv8l-seg 640 dense scenes (>= 1000 candidates per image), 16 per step per GPU, head (16,116,8400)"),
 }
 CONF, IOU, MAX_DET, MASK_CONF = 0.25, 0.45, 300, 0.25
+METRIC = "pre+post images/sec per node, YOLOv8-seg 640 bs64; % HBM roofline"   # BASELINE.json's metric (the seg640 workload)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -192,6 +193,127 @@ def cpu_baseline(cfg, frames, head, proto, n_img, threads, max_seconds=20.0):
     return done / dt, dt, done
 
 
+def event_median_us(fn, n=40, warm=4):
+    """Median of n HIP-event-timed calls of fn on the current stream, in microseconds."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) for a, b in ev)
+    return t[len(t) // 2] * 1e3
+
+
+def nms_targets(device):
+    """North-star target 2 (NMS under 50 us per image at 8400 anchors): `lmi_nms_v8` alone, HIP events around the call
+    (candidate filter + sort/suppress), detection head (B,84,8400), conf 0.25, iou 0.45, max_det 300."""
+    from object_detectors_amd import hip_ops as ops, synth
+    out = {"head": "(B,84,8400) fp32, conf %.2f iou %.2f max_det %d; typical = 40 objects/image (~400 candidates), "
+                   "dense = 110 objects/image (>= 1000 candidates); HIP events around lmi_nms_v8, median of 40" % (CONF, IOU, MAX_DET)}
+    cases = [("us_per_image_b1", 1, 40, (5, 16), False), ("us_per_image_b1_agnostic", 1, 40, (5, 16), True),
+             ("us_per_image_b1_dense", 1, 110, (8, 16), False), ("us_per_image_b1_dense_agnostic", 1, 110, (8, 16), True),
+             ("us_per_call_b64", 64, 40, (5, 16), False), ("us_per_call_b16_dense", 16, 110, (8, 16), False),
+             ("us_per_call_b16_dense_agnostic", 16, 110, (8, 16), True)]
+    for name, B, objects, cluster, agn in cases:
+        rng = np.random.default_rng(1)
+        p = torch.from_numpy(synth.head(rng, B, 80, 0, 640, objects, cluster=cluster)).to(device)
+        res = ops.nms_v8(p, CONF, IOU, nc=80, agnostic=agn, max_det=MAX_DET)
+        out[name] = round(event_median_us(lambda: ops.nms_v8(p, CONF, IOU, nc=80, agnostic=agn, max_det=MAX_DET, out=res)), 1)
+        if B == 1:
+            out[name.replace("us_per_image", "candidates_kept")] = [int((p[:, 4:].amax(1) > CONF).sum().item()), int(res[1][0].item())]
+    return out
+
+
+def letterbox_targets(device, S=640, B=64):
+    """North-star target 1 (letterbox >= 95 % of the HBM roofline): `lmi_letterbox_u8_uniform` alone on cold frames (the
+    calls rotate through 3 distinct source batches, so no source row is still in the 256 MiB Infinity Cache), fp32 NCHW
+    out.  frac_spec = SURVEY 8(d)'s tap-count bytes over time over 8 TB/s; frac_row_granular = whole source rows that
+    hold a tap + output (the bytes that must cross the HBM interface) over the same; traffic_ratio = PMC bytes
+    (profiles/traffic_det640*.json) over the tap-count bytes."""
+    from object_detectors_amd import hip_ops as ops
+    from object_detectors_amd.roofline import letterbox_bytes, letterbox_row_granular_bytes
+    out = {"what": f"{B} frames -> ({B},3,{S},{S}) fp32, cold sources (3 rotating batches), HIP events, median of 40"}
+    g = torch.Generator(device=device)
+    g.manual_seed(11)
+    for tag, h, w, tfile in (("1080p", 1080, 1920, "traffic_det640.json"), ("4k", 2160, 3840, "traffic_det640_4k.json")):
+        fs = [torch.randint(0, 256, (B, h, w, 3), dtype=torch.uint8, device=device, generator=g) for _ in range(3)]
+        o = torch.empty((B, 3, S, S), dtype=torch.float32, device=device)
+        k = [0]
+
+        def rot():
+            k[0] = (k[0] + 1) % 3
+            ops.letterbox(fs[k[0]], (S, S), out=o, pad_value=114, swap_rb=True)
+        us = event_median_us(rot)
+        alg, rowg = B * letterbox_bytes(h, w, S, S, 4), B * letterbox_row_granular_bytes(h, w, S, S, 4)
+        out["us_" + tag] = round(us, 1)
+        out["frac_spec_" + tag] = round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        out["frac_row_granular_" + tag] = round(rowg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        out["GBs_row_granular_" + tag] = round(rowg / (us * 1e-6) / 1e9, 1)
+        tpath = os.path.join(ROOT, "profiles", tfile)
+        if os.path.isfile(tpath):
+            with open(tpath) as f:
+                tr = json.load(f).get("kernels", {}).get("letterbox_kernel", {}).get("traffic")
+            out["traffic_ratio_" + tag] = round(tr / alg, 3) if tr else None
+        del fs, o
+    return out
+
+
+def host_cpus():
+    """What the host offers: the machine's CPU count and model, and the share this process may actually use (affinity
+    mask, cgroup quota, the box's OMP_NUM_THREADS: a one-GPU lease of the pool is allotted 16 CPUs of a much larger host)."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    share = os.cpu_count() or 1
+    try:
+        share = min(share, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            share = min(share, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    omp = os.environ.get("OMP_NUM_THREADS", "")
+    if omp.isdigit() and int(omp) > 0:
+        share = min(share, int(omp))
+    return {"cpu_model": model, "box_cpus": os.cpu_count(), "usable_cpus": share}
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N ...` without a launcher: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process.
+    The parent only counts devices (which does not initialise the GPU) and forwards the child's return code."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        log(f"[bench] --gpus {n} but only {have} GPU(s) visible")
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    log("[bench] launching: " + " ".join(cmd))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,7 +326,9 @@ def main():
                     "(shard.shard_bounds), per-GPU batch per step; --steps is then derived from the shard (BASELINE config 4: "
                     "--workload det640_4k --images 8192)")
     ap.add_argument("--cpu-images", type=int, default=64, help="at most this many images of the workload are timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="stop the CPU sample after this much wall time")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="stop each CPU sample (all usable CPUs, then one thread) after this much wall time")
+    ap.add_argument("--no-targets", dest="targets", action="store_false",
+                    help="skip the `nms` and `letterbox` objects of the line (NMS latency per image, letterbox alone on cold frames)")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--eager", action="store_true", help="launch every kernel of every step from the host instead of replaying "
                     "one captured HIP graph per step (the default; the per-kernel roofline timing then comes from an eager, "
@@ -219,6 +343,10 @@ def main():
                     help="coefficient x prototype product: row-sparse vector-ALU kernel (default) or dense fp32 MFMA tiles "
                          "(measurement of the MFMA variant; the LMI_MASK_LOGITS_MFMA flag of lmi_process_mask_ex)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # invoked plainly with --gpus N: start the N ranks ourselves (one process per GPU) in a FRESH child, before this
+        # process has touched the GPU (it never does), pass the child's output through and leave with its status
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -404,18 +532,30 @@ def main():
             "algorithmic_bytes_per_launch": int(alg), "measured_copy_GBs": round(copy_gbs, 1),
             "frac_of_measured_copy": round(achieved / copy_gbs, 4), "frac_of_achievable_6300": round(achieved / 6300.0, 4)}
 
+    # ---- the north star's other two targets, measured beside the headline (rank 0, after the timed region) ----
+    nms_t = lb_t = None
+    if rank == 0 and args.targets:
+        nms_t = nms_targets(device)
+        lb_t = letterbox_targets(device)
+
     res = None
     if rank == 0:
         cpu = None
         if args.cpu_images > 0 and world == 1:   # the CPU leg is timed at N=1 only
-            threads = min(16, os.cpu_count() or 1)
+            hc = host_cpus()
+            threads = hc["usable_cpus"]     # every CPU this process may use (all cores AND one thread)
+            log(f"[bench] host: {hc['cpu_model']}, {hc['box_cpus']} CPUs in the machine, {threads} usable by this process")
             ips, dt, n_done = cpu_baseline(cfg, frames, head, proto, min(args.cpu_images, B), threads, args.cpu_seconds)
+            ips1, dt1, n1 = cpu_baseline(cfg, frames, head, proto, min(args.cpu_images, B), 1, args.cpu_seconds)
+            torch.set_num_threads(threads)
             cpu = {"value": round(ips, 3), "unit": "images/s", "cores": threads, "kind": "port",
+                   "value_1thread": round(ips1, 3), "box_cpus": hc["box_cpus"], "cpu_model": hc["cpu_model"],
                    "sample": f"first {n_done} images of the same workload through the numpy/torch-CPU oracle "
-                             f"(letterbox+NMS+scale/clip/threshold+process_mask), {dt:.1f}s"}
+                             f"(letterbox+NMS+scale/clip/threshold+process_mask; a reference-equivalent restatement, cv2 / ultralytics "
+                             f"are not installed) on {threads} threads = every CPU this process may use, {dt:.1f}s; then {n1} images on 1 thread, {dt1:.1f}s"}
         pb = sorted(per_block.tolist())
         res = {
-            "metric": "pre+post images/sec per node, YOLOv8-seg 640 bs64; % HBM roofline",
+            "metric": METRIC if args.workload == "seg640" else f"pre+post images/sec per node, {cfg['desc']}; % HBM roofline",
             "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u8->f32 (integer resize, fp32 NMS/masks)", "data": "synthetic",
@@ -432,7 +572,7 @@ def main():
                        "step_overlap": ("letterbox stream joined once per block: step k+1's candidate filter may run beside step k's letterbox"
                                         if (block_graph is not None and args.pipeline_steps and fork and not cfg["nm"]) else "none: every step joins its streams"),
                        "sharding": f"{world} x independent batches, no collective on the hot path"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "nms": nms_t, "letterbox": lb_t,
         }
         print(json.dumps(res), flush=True)
     if dist is not None:

@@ -264,6 +264,7 @@ int lmi_finalize_detections(float *det, const int32_t *count, int batch, int max
  *     the LAST of the nm >= 1 extra channels.  Rows come out as [x, y, w, h, conf, cls, extras...]
  *     (no xyxy conversion).  Suppression is ultralytics' `nms_rotated`: a candidate is dropped when its
  *     probiou with ANY higher-scored candidate (kept or not) is >= iou_thres -- not a greedy pass.
+ *     Limit: min(anchors, max_nms) <= 65536 candidates per image (LMI_ERR_LIMIT beyond).
  *   lmi_finalize_obb  `regularize_rboxes` :436, `scale_boxes(..., xywh=True)` :438, `xywhr2xyxyxyxy` :446
  *     and `M = confs > thres` :448-455.  det is NOT modified; corners [device] fp32 (batch, max_det, 4, 2)
  *     receive the four corner points of rows i < count[b]; keep / keep_count / thres as in

@@ -1283,6 +1283,9 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_rotated(SortNmsParams S
     }
     return;
   }
+  // *gn aliases cd[0] on the global-memory path (in_lds false): every wave must have finished its pair tests, which read
+  // cd[0] for the pairs (0, j), before the marker -- a NaN bit pattern -- lands there
+  __syncthreads();
   if (tid == 0) { wcnt[16] = 0; if (G > 1) *gn = -1; }
   __syncthreads();
 
@@ -1708,6 +1711,9 @@ static int nms_suppress(const NmsCall &C, const void *pred, int batch, int nc, i
   S.scd = reinterpret_cast<float2 *>(C.ws + C.L.off_cd);
   if (rotated) {
     LMI_REQUIRE(nm >= 1, LMI_ERR_BAD_ARG, "lmi_nms_v8_rotated: the angle must be the last of nm >= 1 extra channels");
+    // the near-pair queue of nms_sort_rotated packs (i, j) as two 16-bit halves
+    LMI_REQUIRE((anchors < max_nms ? anchors : max_nms) <= 65536, LMI_ERR_LIMIT,
+                "lmi_nms_v8_rotated: min(anchors %d, max_nms %d) > 65536 candidates per image", anchors, max_nms);
     S.lbox_off = (int)((nms_lds_rot_head(S.lds_keys, max_det) + 15) & ~(size_t)15);
     S.scr_off = (int)((size_t)S.lbox_off + (size_t)S.lds_keys * (16 + 8));
     const size_t lds_rot = (size_t)S.scr_off + kGatherLds + kRotQueueLds;

@@ -195,3 +195,38 @@ def test_rotated_nms_any_number_of_workgroups_per_image():
             n, anchors, rows = ref_rows[b % 12]
             assert int(c[b]) == n and a[b, :n].cpu().numpy().tolist() == anchors, (B, b)
             assert np.array_equal(d[b, :n].cpu().numpy(), rows), (B, b)
+
+
+def test_rotated_nms_global_path_image_among_split_images():
+    """A batch small enough for several workgroups per image (G > 1) that mixes images whose candidates fit the LDS
+    buffers (split over the workgroups) with one that has more than 4096 candidates (group 0 alone, covariances in
+    global memory, where the per-image marker for nms_rotated_emit shares its address with the first covariance
+    entry: the marker may only land after every wave's pair tests).  Every image equals the oracle and the same image
+    of a 130-image call (one workgroup per image)."""
+    from object_detectors_amd import hip_ops as ops
+    rng = np.random.default_rng(11)
+    nc = 5
+    p = synth.head(rng, 4, nc, 1, 448, objects=30)
+    p[:, -1] = (np.tanh(p[:, -1]) * 0.5 + 0.25) * math.pi
+    assert p.shape[2] == 4116
+    cls = p[1:, 4:4 + nc]
+    cls[cls < 0.05] = 0.0                      # images 1..3: only the planted objects are candidates
+    conf, iou = 0.0005, 0.3
+    ref = OO.non_max_suppression_rotated(p, conf, iou, nc=nc, max_det=300)
+    assert (p[0, 4:4 + nc].max(0) > conf).all() and all(0 < len(ref[b][1]) < 300 for b in (1, 2, 3))
+    big = torch.from_numpy(np.concatenate([p] * 33)[:130]).cuda()
+    for B in (130, 4, 2, 1):
+        d, c, a = ops.nms_v8(big[:B].contiguous(), conf, iou, nc=nc, max_det=300, rotated=True)
+        torch.cuda.synchronize()
+        for b in range(B):
+            rows, ra, margin = ref[b % 4]
+            assert margin > 2e-5, "seed puts a decision on the threshold: pick another"
+            n = int(c[b])
+            assert n == len(ra) and a[b, :n].cpu().numpy().tolist() == ra.tolist(), (B, b)
+            assert np.array_equal(d[b, :n].cpu().numpy(), rows), (B, b)
+
+
+def test_rotated_nms_rejects_more_candidates_than_the_pair_queue_indexes():
+    from object_detectors_amd import hip_ops as ops
+    with pytest.raises((ValueError, RuntimeError)):
+        ops.nms_v8(torch.zeros((1, 6, 70000), device="cuda"), 0.5, 0.45, nc=1, max_nms=70000, rotated=True)
