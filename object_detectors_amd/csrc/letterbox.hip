@@ -392,9 +392,11 @@ __global__ __launch_bounds__((TW / 4) * TH) void letterbox_kernel(LbParams P) {
           }
           out[c][k] = TR::make((int)v);   // `.to(uint8)`: truncation (the value lies in [0, 255.00002])
         } else {
-          const int h0 = s00 * a0 + s01 * a1;
-          const int h1 = s10 * a0 + s11 * a1;
-          const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+          // 24-bit multiplies (full rate; the 32-bit v_mul_lo_u32 the compiler picks for plain ints is quarter rate):
+          // taps <= 255, weights <= 2048, h >> 4 <= 32640
+          const uint32_t h0 = __umul24((uint32_t)s00, (uint32_t)a0) + __umul24((uint32_t)s01, (uint32_t)a1);
+          const uint32_t h1 = __umul24((uint32_t)s10, (uint32_t)a0) + __umul24((uint32_t)s11, (uint32_t)a1);
+          const int v = (int)(((__umul24((uint32_t)b0, h0 >> 4) >> 16) + (__umul24((uint32_t)b1, h1 >> 4) >> 16) + 2u) >> 2);
           out[c][k] = TR::make(v);
         }
       }
