@@ -47,6 +47,8 @@ enum lmi_resize_mode { LMI_RESIZE_CV2_LINEAR = 0, LMI_RESIZE_TORCH_BILINEAR = 1,
 /* OR-ed into `mode`: the source frames are single grey planes (uint8 HW, one byte per pixel) */
 #define LMI_SRC_GRAY 0x100
 
+#define LMI_NMS_SWEEP_ONLY 0x100 /* OR-ed into the `rotated` argument of lmi_nms_v8_ex / lmi_nms_suppress_ex */
+
 #define LMI_MAX_DET_CAP 1024   /* largest max_det lmi_nms_v8 accepts */
 #define LMI_MAX_MASK_DIM 32    /* number of prototype channels (nm) the mask kernels are built for */
 #define LMI_MAX_POINT_OPS 16   /* longest operator list lmi_revert_points_f32 accepts */
@@ -181,7 +183,9 @@ int lmi_nms_suppress(const float *pred, int batch, int nc, int nm, int anchors, 
  *               run in fp32 -- the result of `pred.float()` + the fp32 call, without that extra pass over the head.
  *               (The reference would run ultralytics' NMS on the fp16 tensor itself, where `cls * 7680` overflows to
  *               inf from class 9 on and the score threshold is rounded to fp16: deliberately not reproduced.)
- *   rotated     != 0: oriented boxes (lmi_nms_v8_rotated)
+ *   rotated     low byte != 0: oriented boxes (lmi_nms_v8_rotated); OR LMI_NMS_SWEEP_ONLY to keep the one-workgroup
+ *               sorted sweep also where the suppressor-list kernel would run first (agnostic NMS or nc <= 8, and a
+ *               batch that leaves every image >= 4 CUs: same result, for measurement and tests)
  *   fin         NULL, or the arguments of lmi_finalize_detections (below): `ops.scale_boxes` + clip, the per-class
  *               threshold and the survivors' dense ranks (object_detectors/yolov8_lmi/model.py:222-232) then run in
  *               the suppression kernel's epilogue -- rows leave in original-image space and keep / keep_count are

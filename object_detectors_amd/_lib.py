@@ -40,6 +40,7 @@ class lmi_mask_image(C.Structure):
 
 LMI_MASK_LOGITS_MFMA, LMI_MASK_UPSAMPLE_SINGLE, LMI_MASK_PROTO_F16 = 1, 2, 4
 LMI_SRC_GRAY = 0x100
+LMI_NMS_SWEEP_ONLY = 0x100
 
 
 class lmi_point_op(C.Structure):

@@ -82,7 +82,7 @@ __device__ __forceinline__ void ld4(const __half *p, float e[4]) {
 }
 
 struct NmsLayout {
-  size_t off_count, off_keys, off_cls, off_sbox, off_cd, total;
+  size_t off_count, off_keys, off_cls, off_sbox, off_cd, off_flag, total;
   int P;
   int seg;    // anchors per workgroup of the candidate filter = length of its key segment (256, or 64 for odd anchor counts)
   int nblk;   // workgroups (segments) per image
@@ -101,7 +101,8 @@ NmsLayout nms_layout(int batch, int anchors) {
   L.off_keys = o;  o = align_up(o + sizeof(uint64_t) * (size_t)batch * L.P, 256);
   L.off_cls = o;   o = align_up(o + sizeof(int) * (size_t)batch * anchors, 256);
   L.off_sbox = o;  o = align_up(o + sizeof(float4) * (size_t)batch * anchors, 256);
-  L.off_cd = o;    o = align_up(o + sizeof(float2) * (size_t)batch * anchors, 256);  // rotated NMS only
+  L.off_cd = o;    o = align_up(o + sizeof(float2) * (size_t)batch * anchors, 256);  // rotated NMS; with sbox: the suppressor lists
+  L.off_flag = o;  o = align_up(o + sizeof(int) * (size_t)batch, 256);               // list form: images left to the sorted sweep
   L.total = o;
   return L;
 }
@@ -426,7 +427,7 @@ __device__ int top_keys(const int *__restrict__ cnt, int nblk, int seg, int cap,
 }
 
 __device__ int gather_candidates(const int *__restrict__ cnt, int nblk, int seg, int A, int lds_keys, uint64_t *lkeys, uint64_t *gkeys,
-                                 uint64_t *gtmp, int *scr, int &P2, bool &in_lds, int *hist, int &n_total) {
+                                 uint64_t *gtmp, int *scr, int &P2, bool &in_lds, int *hist, int &n_total, int bail_above = 0x7fffffff) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = kSortThreads / 64;
   int *wtot = scr, *ccnt = scr + 32, *cpre = scr + 32 + kGatherChunk;
@@ -442,6 +443,7 @@ __device__ int gather_candidates(const int *__restrict__ cnt, int nblk, int seg,
   __syncthreads();
   n_total = n;
   if (n == 0) return 0;
+  if (n > bail_above) return -1;   // uniform; nothing has been written
   if (n > lds_keys && hist != nullptr) {   // the head of the list only (see top_keys); hist == nullptr: the caller wants all of it
     const int m = top_keys(cnt, nblk, seg, lds_keys, lkeys, gkeys, hist);
     if (m > 0) {
@@ -793,6 +795,8 @@ struct SortNmsParams {
   int lbox_off;  // byte offset of the LDS box buffer (lds_keys float4)
   float2 *scd;   // rotated: covariance c and reach per sorted candidate (global copy)
   int rot_groups; // rotated: workgroups per image that share the pair tests (1: one workgroup does everything)
+  int pair_groups; // axis-aligned: workgroups per image of nms_pair_lists (0: that kernel did not run)
+  int *pair_flags; // [batch] list form: != 0: the image is left to the sorted sweep
 };
 
 // Fused per-image half of `lmi_finalize_detections` (finalize_boxes_kernel is the stand-alone form): the per-class
@@ -832,6 +836,185 @@ __device__ void finalize_epilogue(const SortNmsParams &S, int b, int K, const in
   if (tid == 0) F.keep_count[b] = total;
 }
 
+// The K kept candidates of image b (keys[kpos[t]], t < K, in score order) -> rows x1,y1,x2,y2 (no class offset), conf,
+// cls, coef..., their anchors and the count; with S.fin the boxes leave in original-image space (fused `ops.scale_boxes`
+// + clip) and the per-class threshold / ranks follow (finalize_epilogue).  All kSortThreads lanes call this.
+template <typename InT>
+__device__ __forceinline__ void emit_rows(const SortNmsParams &S, int b, int K, const int *kpos, const uint64_t *keys, const InT *pb,
+                                          unsigned char *smem) {
+  const int tid = threadIdx.x;
+  const int A = S.A;
+  if (tid == 0) S.out_count[b] = K;
+  const int row = 6 + S.nm;
+  float *od = S.out_det + (size_t)b * S.max_det * row;
+  BoxScale bs{};
+  if (S.fin) bs = box_scale(S.F, b);
+  for (int e = tid; e < K * row; e += kSortThreads) {
+    const int t = e / row, col = e - t * row;
+    const uint64_t key = keys[kpos[t]];
+    const uint32_t anchor = ~(uint32_t)key;
+    float v;
+    if (col < 4) {
+      const float c0 = ldf(pb, (size_t)(col & 1) * A + anchor);
+      const float half = ldf(pb, (size_t)(2 + (col & 1)) * A + anchor) / 2.0f;
+      v = (col < 2) ? (c0 - half) : (c0 + half);
+      if (S.fin) v = (col & 1) ? scale_y(bs, v) : scale_x(bs, v);
+    } else if (col == 4) {
+      v = sortable2f((uint32_t)(key >> 32));
+    } else if (col == 5) {
+      v = (float)S.cls_of[(size_t)b * A + anchor];
+    } else {
+      v = ldf(pb, (size_t)(4 + S.nc + (col - 6)) * A + anchor);
+    }
+    od[e] = v;
+    if (col == 0) S.out_anchor[(size_t)b * S.max_det + t] = (int)anchor;
+  }
+  NMS_STAMP(6);
+  if (S.fin) {
+    __syncthreads();   // every reader of the sort buffers is done: the epilogue reuses the start of the LDS
+    finalize_epilogue(S, b, K, kpos, keys, reinterpret_cast<int *>(smem));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Suppressor lists (round 3): the greedy pass of torchvision's nms is the unique fixpoint of
+//     keep_j  =  no kept i with a LARGER key has IoU(i, j) > thr,
+// so WHO could suppress j -- the pairs (i, j), key_i > key_j, IoU > thr -- can be found for all j independently, by as
+// many workgroups as the launch leaves CUs for, before anybody knows who is kept.  That is what one CU cannot do fast
+// for agnostic NMS (all candidates in one class: the sorted sweep's window-vs-kept tests, ~110 k pair tests for a
+// dense image, are bound by the vector ALU of the ONE CU the image's workgroup runs on: 65 us for one image) and what
+// the class-parallel path does inside a workgroup for classes of <= 256 members.  nms_pair_lists: G workgroups per
+// image (host: CUs / batch, at most 64, at least kPairMinGroups -- below that the sweep, which tests against kept boxes
+// only, is cheaper than all n^2 pairs).  Every workgroup gathers the image's candidates in the filter's order (no
+// sort), decodes their (class-offset) boxes into LDS and owns every (16 G)-th column j per wave: lanes hold 64
+// candidates i, the wave's columns come by LDS broadcast, a cheap exact filter (larger key, x and y extents meet: both
+// necessary for IoU > 0) queues the near pairs in LDS, and the queue is evaluated 64 pairs at a time with every lane on
+// the IoU formula.  Hits go to column j's list in global memory -- up to kPairL suppressor indices (positions in the
+// gathered list) and the hit count.  nms_sort_suppress then gathers the same list in the same order, loads the lists
+// and resolves the fixpoint with per-candidate states (kept / dropped / open) in a few rounds, compacts the kept keys and
+// sorts only those.  Images with more candidates than pair_cap() or max_nms, or with a list longer than kPairL, take the
+// sorted sweep as before (nms_pair_lists leaves such an image after counting its candidates).
+constexpr int kPairL = 48;           // suppressors listed per candidate (a multiple of 8: whole 16-byte loads)
+constexpr int kPairCapMax = 2048;    // candidates per image
+constexpr int kPairQueue = 128;      // near pairs a wave queues before it evaluates 64 of them
+constexpr int kPairMinGroups = 16;
+constexpr int kPairMaxGroups = 64;
+// The lists live in the sorted-box and covariance scratch taken together (24 bytes per anchor, contiguous over the batch):
+// image b's area starts 24 A b bytes into it and holds cap lists of kPairL u16, then cap hit counts.  The sweep only uses
+// that scratch for images above its LDS buffers, in the launch AFTER nms_resolve_lists has consumed the lists.
+__host__ __device__ inline int pair_cap(int anchors) {
+  const long c = ((long)anchors * 24 / (2 * kPairL + 4)) & ~7L;
+  return c < kPairCapMax ? (int)c : kPairCapMax;
+}
+__device__ __forceinline__ unsigned char *pair_area(const SortNmsParams &S, int b) {
+  return reinterpret_cast<unsigned char *>(S.sbox) + (size_t)b * 24 * S.A;
+}
+constexpr size_t resolve_lds_bytes(int p2cap, int max_det, int cap) {
+  return (size_t)p2cap * 8 + (size_t)((max_det + 3) & ~3) * 4 + (size_t)((cap + 15) & ~15) + 32 * 4 + kGatherLds;
+}
+constexpr size_t pair_lds_bytes(int p2cap) { return (size_t)p2cap * (8 + 16 + 4) + (size_t)(kSortThreads / 64) * kPairQueue * 4 + kGatherLds; }
+
+template <typename InT>
+__global__ __launch_bounds__(kSortThreads) void nms_pair_lists(SortNmsParams S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NW = kSortThreads / 64;
+  const int G = S.pair_groups;
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int A = S.A, C = 4 + S.nc + S.nm;
+  const int cap = pair_cap(A), p2cap = next_pow2(cap);
+  uint64_t *lkeys = reinterpret_cast<uint64_t *>(smem);
+  float4 *lbox = reinterpret_cast<float4 *>(smem + (size_t)p2cap * 8);
+  int *lcnt = reinterpret_cast<int *>(smem + (size_t)p2cap * 24);
+  uint32_t *queue = reinterpret_cast<uint32_t *>(smem + (size_t)p2cap * 28) + wave * kPairQueue;
+  int *scr = reinterpret_cast<int *>(smem + (size_t)p2cap * 28 + (size_t)NW * kPairQueue * 4);
+  const InT *pb = reinterpret_cast<const InT *>(S.pred) + (size_t)b * C * A;
+
+  int P2 = 0, n_total = 0;
+  bool in_lds = true;
+  NMS_STAMP(10);
+  const int n = gather_candidates(S.blk_count + (size_t)b * S.nblk, S.nblk, S.seg, A, p2cap, lkeys, S.keys + (size_t)b * S.P, nullptr, scr,
+                                  P2, in_lds, nullptr, n_total, min(cap, S.max_nms));
+  if (n <= 0) return;   // no candidates, or more than the lists serve: the sorted sweep takes this image
+  NMS_STAMP(11);
+  for (int i = tid; i < n; i += kSortThreads) {
+    const uint32_t anchor = ~(uint32_t)lkeys[i];
+    const float cx = ldf(pb, anchor), cy = ldf(pb, (size_t)A + anchor), w = ldf(pb, (size_t)2 * A + anchor), h = ldf(pb, (size_t)3 * A + anchor);
+    const float hw = w / 2.0f, hh = h / 2.0f;
+    const float c = S.agnostic ? 0.0f : (float)S.cls_of[(size_t)b * A + anchor] * S.max_wh;
+    lbox[i] = make_float4((cx - hw) + c, (cy - hh) + c, (cx + hw) + c, (cy + hh) + c);   // as the sweep decodes them
+    lcnt[i] = 0;
+  }
+  __syncthreads();
+  NMS_STAMP(12);
+
+  uint16_t *plist = reinterpret_cast<uint16_t *>(pair_area(S, b));
+  int *pcnt = reinterpret_cast<int *>(pair_area(S, b) + (size_t)cap * kPairL * 2);
+  const int nw = NW * G, w0 = g * NW + wave;   // this wave's columns: w0, w0 + nw, ...
+  int qn = 0;                                  // queued pairs (wave-uniform)
+  auto evaluate = [&](int cnt) {
+    if (lane < cnt) {
+      const uint32_t pr = queue[lane];
+      const int i = (int)(pr & 0xffffu), j = (int)(pr >> 16);
+      const float4 bi = lbox[i], bj = lbox[j];
+      if (iou_gt(bi.x, bi.y, bi.z, bi.w, (bi.z - bi.x) * (bi.w - bi.y), bj.x, bj.y, bj.z, bj.w, (bj.z - bj.x) * (bj.w - bj.y), S.iou_thr)) {
+        const int slot = atomicAdd(&lcnt[j], 1);   // column j belongs to this wave alone
+        if (slot < kPairL) plist[(size_t)j * kPairL + slot] = (uint16_t)i;
+      }
+    }
+  };
+  // Cheap test: i has the larger key and the boxes' extents meet strictly in x and in y -- necessary for inter > 0 in
+  // iou_gt (min(x2) > max(x1) implies both cross comparisons; a NaN coordinate makes IoU NaN and the formula says "no"
+  // whatever this test says).  Plain comparisons joined by & (no short-circuit: the operands are in registers).  (An
+  // area-ratio test on top -- IoU <= min(area) / max(area) -- was tried: fewer pairs reach the formula, but the loop is
+  // bound by the cheap tests, not by the formula: no gain.)
+  auto push = [&](bool near, uint64_t m, int i, int j) {
+    if (near) queue[qn + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)i | ((uint32_t)j << 16);
+    qn += __builtin_popcountll(m);
+    __builtin_amdgcn_wave_barrier();
+    if (qn >= 64) {
+      evaluate(64);
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t t = lane < qn - 64 ? queue[64 + lane] : 0u;
+      __builtin_amdgcn_wave_barrier();
+      if (lane < qn - 64) queue[lane] = t;
+      __builtin_amdgcn_wave_barrier();
+      qn -= 64;
+    }
+  };
+  // Columns in pairs held in registers (a wave has n / (16 G) of them: one or two with 64 workgroups per image), the
+  // candidates i streamed past them 128 at a time: the only LDS reads in the loop are the lanes' own (key, box), and
+  // those of the next block do not depend on this block's tests.
+  const int ncol = n > w0 ? (n - w0 + nw - 1) / nw : 0;
+  for (int c = 0; c < ncol; c += 2) {
+    const int j0 = w0 + c * nw, j1 = j0 + nw;
+    const bool two = j1 < n;
+    const uint64_t kj0 = lkeys[j0], kj1 = two ? lkeys[j1] : ~0ull;   // ~0: no key is larger, the second column never hits
+    const float4 bj0 = lbox[j0], bj1 = lbox[two ? j1 : j0];
+    for (int i0 = 0; i0 < n; i0 += 128) {
+      const int ia = i0 + lane, ib = ia + 64;
+      const uint64_t ka = ia < n ? lkeys[ia] : 0ull, kb = ib < n ? lkeys[ib] : 0ull;   // 0: below every key
+      const float4 ba = lbox[min(ia, n - 1)], bb = lbox[min(ib, n - 1)];
+      const bool a0 = (ka > kj0) & (ba.z > bj0.x) & (bj0.z > ba.x) & (ba.w > bj0.y) & (bj0.w > ba.y);
+      const bool a1 = (ka > kj1) & (ba.z > bj1.x) & (bj1.z > ba.x) & (ba.w > bj1.y) & (bj1.w > ba.y);
+      const bool b0 = (kb > kj0) & (bb.z > bj0.x) & (bj0.z > bb.x) & (bb.w > bj0.y) & (bj0.w > bb.y);
+      const bool b1 = (kb > kj1) & (bb.z > bj1.x) & (bj1.z > bb.x) & (bb.w > bj1.y) & (bj1.w > bb.y);
+      const uint64_t ma0 = __ballot(a0), ma1 = __ballot(a1), mb0 = __ballot(b0), mb1 = __ballot(b1);
+      if ((ma0 | ma1 | mb0 | mb1) == 0ull) continue;
+      if (ma0) push(a0, ma0, ia, j0);
+      if (ma1) push(a1, ma1, ia, j1);
+      if (mb0) push(b0, mb0, ib, j0);
+      if (mb1) push(b1, mb1, ib, j1);
+    }
+  }
+  NMS_STAMP(13);
+  __builtin_amdgcn_wave_barrier();
+  evaluate(qn);
+  __builtin_amdgcn_wave_barrier();
+  for (int j = w0 + nw * lane; j < n; j += nw * 64) pcnt[j] = lcnt[j];
+  NMS_STAMP(14);
+}
+
 // Position (0..255) of the t-th set bit (t counted from 0, t < number of set bits) of the 256-bit set am[0..3];
 // ac[q] = popcount(am[q]).
 __device__ __forceinline__ int nth_alive(const uint64_t (&am)[4], const int (&ac)[4], int t) {
@@ -856,6 +1039,147 @@ __device__ __forceinline__ int nth_alive(const uint64_t (&am)[4], const int (&ac
   return 64 * q + pos;
 }
 
+// Second half of the list form (see nms_pair_lists): one workgroup per image gathers the candidates again (same order),
+// loads their suppressor lists and resolves the greedy fixpoint with per-candidate states; the kept keys are compacted,
+// sorted (only they) and written out like nms_sort_suppress does.  A kernel of its own, lean: inside nms_sort_suppress the
+// two lists of kPairL indices per lane cost that kernel's other paths registers and spills (its candidate gather alone
+// went from 5 to 11 us).  Images it cannot serve -- more candidates than the lists hold, or a list longer than kPairL --
+// are flagged for the launch of nms_sort_suppress that follows (which leaves every other image at once).
+// LDS: lds_keys keys | max_det positions | cap state bytes + 16 wave totals | the gather's scratch.
+__device__ __forceinline__ int *pair_flag(const SortNmsParams &S, int b) { return S.pair_flags + b; }
+
+template <typename InT>
+__global__ __launch_bounds__(kSortThreads) void nms_resolve_lists(SortNmsParams S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int A = S.A, C = 4 + S.nc + S.nm;
+  const int cap = pair_cap(A), p2cap = next_pow2(cap);
+  uint64_t *lkeys = reinterpret_cast<uint64_t *>(smem);
+  int *kpos = reinterpret_cast<int *>(smem + (size_t)p2cap * 8);
+  unsigned char *state = reinterpret_cast<unsigned char *>(kpos + ((S.max_det + 3) & ~3));   // 0 open, 1 kept, 2 dropped
+  int *misc = reinterpret_cast<int *>(state + ((cap + 15) & ~15));                             // wave totals of the compaction
+  int *scr = misc + 32;
+  const InT *pb = reinterpret_cast<const InT *>(S.pred) + (size_t)b * C * A;
+  const uint16_t *plist = reinterpret_cast<const uint16_t *>(pair_area(S, b));
+  const int *pcnt = reinterpret_cast<const int *>(pair_area(S, b) + (size_t)cap * kPairL * 2);
+
+  NMS_STAMP(0);
+  int P2 = 0, n_total = 0;
+  bool in_lds = true;
+  const int n = gather_candidates(S.blk_count + (size_t)b * S.nblk, S.nblk, S.seg, A, p2cap, lkeys, S.keys + (size_t)b * S.P, nullptr, scr,
+                                  P2, in_lds, nullptr, n_total, min(cap, S.max_nms));
+  NMS_STAMP(1);
+  if (n < 0) {            // nms_pair_lists left this image too
+    if (tid == 0) pair_flag(S, b)[0] = 1;
+    return;
+  }
+  int K = 0;
+  if (n > 0) {
+      constexpr int NW = kSortThreads / 64;
+      int cnt[2] = {0, 0}, st[2] = {3, 3};   // 3: no candidate
+      uint64_t mykey[2] = {0ull, 0ull};
+      uint4 lst[2][kPairL / 8];
+      int over = 0;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int j = tid + kSortThreads * u;
+        if (j < n) {
+          cnt[u] = pcnt[j];
+          over |= cnt[u] > kPairL ? 1 : 0;
+          mykey[u] = lkeys[j];
+          const uint4 *lp = reinterpret_cast<const uint4 *>(plist + (size_t)j * kPairL);
+#pragma unroll
+          for (int w4 = 0; w4 < kPairL / 8; ++w4)
+            if (8 * w4 < cnt[u] && cnt[u] <= kPairL) lst[u][w4] = lp[w4];
+          st[u] = cnt[u] == 0 ? 1 : 0;
+          state[j] = (unsigned char)st[u];
+        }
+      }
+      over = __syncthreads_or(over);   // also publishes the states
+      NMS_STAMP(20);
+      if (over) NMS_STAMP(25);
+      if (!over) {
+        // A candidate without suppressors is kept; one with a kept suppressor is dropped; one whose suppressors are all
+        // dropped is kept.  A state changes once, from open to its final value, and every open candidate only waits for
+        // candidates with larger keys, so the open candidate with the largest key can always be settled: no barrier is
+        // needed for progress.  Every wave looks at its own open candidates again and again -- the others' states are
+        // read from LDS as they are at that moment: a final state, or "open" (then the lane looks again) -- until its own
+        // are settled; the workgroup meets once, afterwards.  (With a workgroup barrier per round: 7-9 rounds, 8 us for a
+        // dense image.)  The bound only guards against a stuck wave; whoever is still open then sends the image to the
+        // sweep.
+        for (int it = 0; it < 4096; ++it) {
+          if (__ballot(st[0] == 0 || st[1] == 0) == 0ull) break;   // this wave's candidates are settled
+          bool progress = false;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const bool open = st[u] == 0;
+            bool any_kept = false, all_dropped = true;
+#pragma unroll
+            for (int w4 = 0; w4 < kPairL / 8; ++w4) {
+              if (__ballot(open && 8 * w4 < cnt[u]) == 0ull) break;   // uniform: nobody in the wave has that many
+              const uint32_t ws[4] = {lst[u][w4].x, lst[u][w4].y, lst[u][w4].z, lst[u][w4].w};
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                if (open && 8 * w4 + e < cnt[u]) {
+                  const int sv = state[(ws[e >> 1] >> (16 * (e & 1))) & 0xffffu];
+                  any_kept |= sv == 1;
+                  all_dropped &= sv == 2;
+                }
+              }
+            }
+            if (open && (any_kept || all_dropped)) {
+              st[u] = any_kept ? 2 : 1;
+              state[tid + kSortThreads * u] = (unsigned char)st[u];
+              progress = true;
+            }
+          }
+          __asm__ volatile("" ::: "memory");                            // the states are read afresh next time
+          if (__ballot(progress) == 0ull) __builtin_amdgcn_s_sleep(2);  // waiting for other waves' candidates
+        }
+        if (__syncthreads_or(st[0] == 0 || st[1] == 0)) {               // (cannot happen short of the bound)
+          if (tid == 0) pair_flag(S, b)[0] = 1;
+          return;
+        }
+        NMS_STAMP(21);
+        // the kept keys, compacted to the head of the list (every lane holds its candidates' keys), then sorted: the
+        // output order and the S.max_det cut
+        const int mine = (st[0] == 1 ? 1 : 0) + (st[1] == 1 ? 1 : 0);
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int t = __shfl_up(incl, d);
+          if (lane >= d) incl += t;
+        }
+        if (lane == 63) misc[wave] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < NW; ++w) {
+          const int t = misc[w];
+          if (w < wave) before += t;
+          total += t;
+        }
+        int idx = before + incl - mine;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (st[u] == 1) lkeys[idx++] = mykey[u];
+        const int PK = next_pow2(max(total, 1));
+        for (int i = total + tid; i < PK; i += kSortThreads) lkeys[i] = 0ull;
+        __syncthreads();
+        bitonic_desc_lds(lkeys, PK);
+        K = min(total, S.max_det);
+        for (int t = tid; t < K; t += kSortThreads) kpos[t] = t;   // the kept keys lie sorted at the head of the list
+        __syncthreads();
+        NMS_STAMP(22);
+      } else {
+        if (tid == 0) pair_flag(S, b)[0] = 1;   // a list ran over: the sorted sweep
+        return;
+      }
+  }
+  if (tid == 0) pair_flag(S, b)[0] = 0;
+  emit_rows<InT>(S, b, K, kpos, lkeys, pb, smem);
+}
+
 template <typename InT>
 __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams S) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -876,6 +1200,8 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int A = S.A, C = 4 + S.nc + S.nm;
+  // behind nms_pair_lists + nms_resolve_lists: only the images those two could not serve (uniform over the workgroup)
+  if (S.pair_groups > 0 && pair_flag(S, b)[0] == 0) return;
   const InT *pb = reinterpret_cast<const InT *>(S.pred) + (size_t)b * C * A;
   uint64_t *gkeys = S.keys + (size_t)b * S.P;
   float4 *sbox = S.sbox + (size_t)b * A;
@@ -902,14 +1228,14 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
     if (tid == 0) *sK = 0;
     __syncthreads();
 
+    int K = 0;
+    bool done = false;
     // ---- class-parallel suppression on the UNSORTED candidates (see class_parallel_nms): per-class NMS, few classes,
     //      every candidate inside the max_nms cut, the candidates in the lower half of the LDS key buffer (the upper
     //      half takes the grouped copy) and room for the scratch behind the grouped boxes -------------------------------
     const int ncp = (S.nc + 1) & ~1;
     const bool cp_try = in_lds && !S.agnostic && S.nc <= kCpMaxClasses && P2 <= 2 * kSortThreads && n <= S.max_nms &&
                         2 * P2 <= S.lds_keys && (size_t)(S.lds_keys - P2) * sizeof(float4) >= cp_bytes(P2, ncp);
-    int K = 0;
-    bool done = false;
     if (cp_try) {
       const CpScratch CP = cp_carve(reinterpret_cast<unsigned char *>(lbox + P2), P2, ncp);
       done = class_parallel_nms(CP, lkeys, lkeys + P2, lbox, pb, S.cls_of + (size_t)b * A, A, n, P2, ncp, S.max_det, S.max_wh, S.iou_thr, sK);
@@ -1085,38 +1411,7 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_suppress(SortNmsParams 
     K = attempt(n, P2, in_lds);
   }
 
-  // ---- emit rows: x1,y1,x2,y2 (no class offset), conf, cls, coef... ---------------------------------
-  if (tid == 0) S.out_count[b] = K;
-  const int row = 6 + S.nm;
-  float *od = S.out_det + (size_t)b * S.max_det * row;
-  BoxScale bs{};
-  if (S.fin) bs = box_scale(S.F, b);   // fused `ops.scale_boxes` + clip: the rows leave in original-image space
-  for (int e = tid; e < K * row; e += kSortThreads) {
-    const int t = e / row, col = e - t * row;
-    const int pos = kpos[t];
-    const uint64_t key = in_lds ? lkeys[pos] : gkeys[pos];
-    const uint32_t anchor = ~(uint32_t)key;
-    float v;
-    if (col < 4) {
-      const float c0 = ldf(pb, (size_t)(col & 1) * A + anchor);
-      const float half = ldf(pb, (size_t)(2 + (col & 1)) * A + anchor) / 2.0f;
-      v = (col < 2) ? (c0 - half) : (c0 + half);
-      if (S.fin) v = (col & 1) ? scale_y(bs, v) : scale_x(bs, v);
-    } else if (col == 4) {
-      v = sortable2f((uint32_t)(key >> 32));
-    } else if (col == 5) {
-      v = (float)S.cls_of[(size_t)b * A + anchor];
-    } else {
-      v = ldf(pb, (size_t)(4 + S.nc + (col - 6)) * A + anchor);
-    }
-    od[e] = v;
-    if (col == 0) S.out_anchor[(size_t)b * S.max_det + t] = (int)anchor;
-  }
-  NMS_STAMP(6);
-  if (S.fin) {
-    __syncthreads();   // every reader of the sort buffers is done: the epilogue reuses the start of the LDS
-    finalize_epilogue(S, b, K, kpos, in_lds ? lkeys : gkeys, reinterpret_cast<int *>(smem));
-  }
+  emit_rows<InT>(S, b, K, kpos, in_lds ? lkeys : gkeys, pb, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1592,6 +1887,10 @@ static int nms_device_state(NmsDeviceState **out) {
       e = hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_rotated<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNmsLdsRotMax);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_rotated<__half>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNmsLdsRotMax);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(nms_pair_lists<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(kPairCapMax));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(nms_pair_lists<__half>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(kPairCapMax));
     if (e != hipSuccess) { lmi_set_error("lmi_nms: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LMI_ERR_LAUNCH; }
     void *ptr = nullptr;
     e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
@@ -1693,8 +1992,9 @@ static void fin_params(const lmi_finalize_args *fin, float *det, const int32_t *
 
 // second half: sort + suppression (+ the fused finalize), one workgroup per image (latency / LDS-bound, next to no HBM traffic)
 static int nms_suppress(const NmsCall &C, const void *pred, int batch, int nc, int nm, int anchors, double iou_thres, int agnostic,
-                        int max_det, int max_nms, float max_wh, float *out_det, int32_t *out_count, int32_t *out_anchor, int rotated,
+                        int max_det, int max_nms, float max_wh, float *out_det, int32_t *out_count, int32_t *out_anchor, int rotated_flags,
                         const lmi_finalize_args *fin) {
+  const int rotated = (rotated_flags & 0xff) ? 1 : 0, sweep_only = (rotated_flags & LMI_NMS_SWEEP_ONLY) ? 1 : 0;
   // torchvision compares the fp32 IoU against the threshold as a double: use the largest fp32 <= thr.
   // nms_rotated compares `ious.max(0) < threshold` in fp32 (tensor vs Python float): the threshold rounded to fp32.
   float thr = (float)iou_thres;
@@ -1709,6 +2009,7 @@ static int nms_suppress(const NmsCall &C, const void *pred, int batch, int nc, i
   S.sbox = C.sbox; S.blk_count = C.blk_count; S.nblk = C.L.nblk; S.seg = C.L.seg; S.out_det = out_det; S.out_count = out_count; S.out_anchor = out_anchor;
   S.lds_keys = C.L.P < kSortLdsCap ? C.L.P : kSortLdsCap;
   S.scd = reinterpret_cast<float2 *>(C.ws + C.L.off_cd);
+  S.pair_flags = reinterpret_cast<int *>(C.ws + C.L.off_flag);
   if (rotated) {
     LMI_REQUIRE(nm >= 1, LMI_ERR_BAD_ARG, "lmi_nms_v8_rotated: the angle must be the last of nm >= 1 extra channels");
     // the near-pair queue of nms_sort_rotated packs (i, j) as two 16-bit halves
@@ -1731,14 +2032,36 @@ static int nms_suppress(const NmsCall &C, const void *pred, int batch, int nc, i
     else hipLaunchKernelGGL(nms_rotated_emit<float>, dim3(batch), dim3(kSortThreads), 0, C.s, S);
     return lmi_check_launch("nms_rotated_emit");
   }
-  S.lbox_off = (int)((nms_lds_small(S.lds_keys, max_det) + 15) & ~(size_t)15);
-  S.scr_off = (int)((size_t)S.lbox_off + (size_t)S.lds_keys * 16);
-  size_t lds = (size_t)S.scr_off + kGatherLds;
   if (fin) {
     S.fin = 1;
     fin_params(fin, out_det, out_count, batch, max_det, 6 + nm, nc, S.F);
-    if (lds < sizeof(int) * 64) lds = sizeof(int) * 64;   // the epilogue's LDS scratch
   }
+  // Suppressor lists first (nms_pair_lists + nms_resolve_lists) where the sorted sweep is slow and CUs would idle: agnostic
+  // NMS and models with a handful of classes (classes too large for the class-parallel path), batches that leave every
+  // image at least kPairMinGroups workgroups.  The sweep kernel below then only serves the images those two flagged.
+  // LMI_NMS_SWEEP_ONLY (measurement, tests): never.
+  S.pair_groups = 0;
+  if ((agnostic || nc <= 8) && pair_cap(anchors) >= 64 && !sweep_only) {
+    int G = D->cu_count / batch;
+    if (G > kPairMaxGroups) G = kPairMaxGroups;
+    if (G >= kPairMinGroups) {
+      S.pair_groups = G;
+      const int p2cap = next_pow2(pair_cap(anchors));
+      const size_t lds_pairs = pair_lds_bytes(p2cap), lds_res = resolve_lds_bytes(p2cap, max_det, pair_cap(anchors));
+      if (C.half) hipLaunchKernelGGL(nms_pair_lists<__half>, dim3(batch * G), dim3(kSortThreads), lds_pairs, C.s, S);
+      else hipLaunchKernelGGL(nms_pair_lists<float>, dim3(batch * G), dim3(kSortThreads), lds_pairs, C.s, S);
+      int rcp = lmi_check_launch("nms_pair_lists");
+      if (rcp) return rcp;
+      if (C.half) hipLaunchKernelGGL(nms_resolve_lists<__half>, dim3(batch), dim3(kSortThreads), lds_res, C.s, S);
+      else hipLaunchKernelGGL(nms_resolve_lists<float>, dim3(batch), dim3(kSortThreads), lds_res, C.s, S);
+      rcp = lmi_check_launch("nms_resolve_lists");
+      if (rcp) return rcp;
+    }
+  }
+  S.lbox_off = (int)((nms_lds_small(S.lds_keys, max_det) + 15) & ~(size_t)15);
+  S.scr_off = (int)((size_t)S.lbox_off + (size_t)S.lds_keys * 16);
+  size_t lds = (size_t)S.scr_off + kGatherLds;
+  if (fin && lds < sizeof(int) * 64) lds = sizeof(int) * 64;   // the epilogue's LDS scratch
   if (C.half) hipLaunchKernelGGL(nms_sort_suppress<__half>, dim3(batch), dim3(kSortThreads), lds, C.s, S);
   else hipLaunchKernelGGL(nms_sort_suppress<float>, dim3(batch), dim3(kSortThreads), lds, C.s, S);
   int rc = lmi_check_launch("nms_sort_suppress");
@@ -1763,10 +2086,10 @@ int lmi_nms_suppress_ex(const void *pred, int pred_dtype, int batch, int nc, int
   if (rc) return rc;
   rc = nms_check_suppress(out_det, out_count, out_anchor, iou_thres, max_det, max_nms);
   if (rc) return rc;
-  rc = fin_check(fin, batch, rotated);
+  rc = fin_check(fin, batch, rotated & 0xff);
   if (rc) return rc;
   return nms_suppress(C, pred, batch, nc, nm, anchors, iou_thres, agnostic, max_det, max_nms, max_wh, out_det, out_count, out_anchor,
-                      rotated ? 1 : 0, fin);
+                      rotated, fin);
 }
 
 int lmi_nms_v8_ex(const void *pred, int pred_dtype, int batch, int nc, int nm, int anchors, float conf_thres, double iou_thres,
@@ -1777,12 +2100,12 @@ int lmi_nms_v8_ex(const void *pred, int pred_dtype, int batch, int nc, int nm, i
   if (rc) return rc;
   rc = nms_check_suppress(out_det, out_count, out_anchor, iou_thres, max_det, max_nms);
   if (rc) return rc;
-  rc = fin_check(fin, batch, rotated);
+  rc = fin_check(fin, batch, rotated & 0xff);
   if (rc) return rc;
   rc = nms_decode(C, pred, batch, nc, nm, anchors, conf_thres);
   if (rc) return rc;
   return nms_suppress(C, pred, batch, nc, nm, anchors, iou_thres, agnostic, max_det, max_nms, max_wh, out_det, out_count, out_anchor,
-                      rotated ? 1 : 0, fin);
+                      rotated, fin);
 }
 
 int lmi_nms_decode(const float *pred, int batch, int nc, int nm, int anchors, float conf_thres, void *workspace,

@@ -288,7 +288,7 @@ def _finalize_setup(b: int, max_det: int, nc: int, dev, model_hw, orig_hw, thres
 
 def nms_v8(pred: torch.Tensor, conf_thres: float, iou_thres: float = 0.45, agnostic: bool = False, max_det: int = 300,
            nc: int = 0, max_nms: int = 30000, max_wh: float = 7680.0, out=None, rotated: bool = False,
-           decode_done: Optional[torch.cuda.Event] = None, finalize: Optional[dict] = None):
+           decode_done: Optional[torch.cuda.Event] = None, finalize: Optional[dict] = None, sweep_only: bool = False):
     """`ops.non_max_suppression` on the head output (B, 4+nc+nm, A), fp32 or fp16 (an fp16 head is read as it is,
     every value promoted to fp32 in the kernels: the result of `pred.float()` without that pass).  rotated=True:
     oriented boxes (xywh + angle as the last extra channel, ultralytics' nms_rotated on probiou), rows stay xywh.
@@ -298,6 +298,9 @@ def nms_v8(pred: torch.Tensor, conf_thres: float, iou_thres: float = 0.45, agnos
     finalize: dict(model_hw=, orig_hw=, thres=[, pad_round=True, with_slots=True, out=None]) -- the arguments of
     finalize_detections: scale_boxes + clip, class threshold and survivor ranks then run in the suppression kernel's
     epilogue (one launch less, same results) and the call returns a 4th value, finalize_detections' result dict.
+
+    sweep_only: LMI_NMS_SWEEP_ONLY -- keep the one-workgroup sorted sweep where the suppressor-list kernel would run
+    first (same result; measurement and tests).
 
     Returns (det (B,max_det,6+nm) fp32, count (B,) int32, anchor (B,max_det) int32), all on the
     device; rows >= count[b] are unspecified.  `out` = a previous result tuple of the same shapes
@@ -340,12 +343,12 @@ def nms_v8(pred: torch.Tensor, conf_thres: float, iou_thres: float = 0.45, agnos
         check(_L.lmi_nms_decode_ex(pred.data_ptr(), pdt, b, nc, nm, a, float(conf_thres), ws.data_ptr(), ws.numel(), st))
         decode_done.record()
         check(_L.lmi_nms_suppress_ex(pred.data_ptr(), pdt, b, nc, nm, a, float(iou_thres), int(agnostic), int(max_det), int(max_nms),
-                                     float(max_wh), int(rotated), fin_ptr, det.data_ptr(), count.data_ptr(), anchor.data_ptr(),
-                                     ws.data_ptr(), ws.numel(), st))
+                                     float(max_wh), int(rotated) | (_lib.LMI_NMS_SWEEP_ONLY if sweep_only else 0), fin_ptr, det.data_ptr(),
+                                     count.data_ptr(), anchor.data_ptr(), ws.data_ptr(), ws.numel(), st))
     else:
         check(_L.lmi_nms_v8_ex(pred.data_ptr(), pdt, b, nc, nm, a, float(conf_thres), float(iou_thres), int(agnostic), int(max_det),
-                               int(max_nms), float(max_wh), int(rotated), fin_ptr, det.data_ptr(), count.data_ptr(), anchor.data_ptr(),
-                               ws.data_ptr(), ws.numel(), st))
+                               int(max_nms), float(max_wh), int(rotated) | (_lib.LMI_NMS_SWEEP_ONLY if sweep_only else 0), fin_ptr, det.data_ptr(),
+                               count.data_ptr(), anchor.data_ptr(), ws.data_ptr(), ws.numel(), st))
     if finalize is not None:
         return det, count, anchor, fin_res
     return det, count, anchor

@@ -132,8 +132,9 @@ def test_letterbox_random_geometries_one_ragged_batch(ops, seed):
             assert bad.shape[0] == 0, f"frame {sizes[b]} -> {(dh, dw)} stretch={stretch}: {bad.shape[0]} mismatches, first {bad[:4].tolist()}"
 
 
+@pytest.mark.parametrize("sweep_only", [False, True])   # suppressor lists first (agnostic / few classes) or the sorted sweep alone
 @pytest.mark.parametrize("seed", sweep_seeds(77))
-def test_nms_random_configurations_with_score_ties(ops, seed):
+def test_nms_random_configurations_with_score_ties(ops, seed, sweep_only):
     """Differential sweep over head shapes and NMS settings; scores quantised to 1/128 so that many candidates tie
     and the order rule (equal scores keep anchor order, torch.sort stable) decides the kept set."""
     rng = np.random.default_rng(seed)
@@ -148,7 +149,7 @@ def test_nms_random_configurations_with_score_ties(ops, seed):
         iou = float(rng.choice([0.45, 0.3, 0.7, 0.0, 1.0]))
         agnostic = bool(rng.integers(0, 2))
         max_det = int(rng.choice([300, 5, 1, 64]))
-        det, count, anchor = ops.nms_v8(dev(p), conf, iou, agnostic=agnostic, max_det=max_det, nc=nc)
+        det, count, anchor = ops.nms_v8(dev(p), conf, iou, agnostic=agnostic, max_det=max_det, nc=nc, sweep_only=sweep_only)
         torch.cuda.synchronize()
         ref = ON.non_max_suppression(p, conf, iou, agnostic=agnostic, max_det=max_det, nc=nc)
         for b in range(B):
@@ -339,8 +340,9 @@ def test_nms_class_parallel_path_boundaries(ops, seed):
             assert n == 0 or np.abs(det[0, :n].cpu().numpy() - rd).max() <= 1e-3, tag
 
 
+@pytest.mark.parametrize("sweep_only", [True, False])
 @pytest.mark.parametrize("seed", sweep_seeds(1212))
-def test_nms_sorted_sweep_windows(ops, seed):
+def test_nms_sorted_sweep_windows(ops, seed, sweep_only):
     """The sweep over the sorted list (agnostic NMS; per-class NMS with few, large classes, which the class-parallel
     path hands over): windows of 256 candidates, of which the first 64 still alive are resolved per step.  Scenes that
     leave fewer / more than 64 alive in a window, more than one window, a max_det cut inside a step, one class only."""
@@ -348,7 +350,7 @@ def test_nms_sorted_sweep_windows(ops, seed):
     for nc, objects, agn, md in [(1, 40, False, 300), (2, 100, False, 300), (3, 15, False, 300), (80, 110, True, 300),
                                  (5, 60, True, 300), (2, 100, True, 37), (4, 150, False, 64)]:
         p = synth.head(rng, 2, nc, 0, 320, objects, cluster=(6, 16))
-        det, count, anchor = ops.nms_v8(dev(p), 0.25, 0.45, agnostic=agn, max_det=md, nc=nc)
+        det, count, anchor = ops.nms_v8(dev(p), 0.25, 0.45, agnostic=agn, max_det=md, nc=nc, sweep_only=sweep_only)
         torch.cuda.synchronize()
         ref = ON.non_max_suppression(p, 0.25, 0.45, agnostic=agn, max_det=md, nc=nc)
         for b, (rd, ra) in enumerate(ref):
