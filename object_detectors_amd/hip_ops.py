@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import functools
 import struct
+import threading
 from typing import List, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -29,15 +30,17 @@ class _WorkspaceCache:
     def __init__(self, limit: int = 32):
         self._buf = {}
         self._limit = limit
+        self._lock = threading.Lock()       # host threads that drive their own streams share this cache
 
     def get(self, device: torch.device, tag: str, nbytes: int) -> torch.Tensor:
         key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
-        t = self._buf.pop(key, None)
-        if t is None or t.numel() < nbytes:
-            t = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=device)
-        self._buf[key] = t                  # most recently used last (dicts keep insertion order)
-        while len(self._buf) > self._limit:
-            self._buf.pop(next(iter(self._buf)))
+        with self._lock:
+            t = self._buf.pop(key, None)
+            if t is None or t.numel() < nbytes:
+                t = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=device)
+            self._buf[key] = t              # most recently used last (dicts keep insertion order)
+            while len(self._buf) > self._limit:
+                self._buf.pop(next(iter(self._buf)))
         return t
 
 
@@ -53,17 +56,20 @@ class _DescriptorCache:
     def __init__(self, limit: int = 16):
         self._d = {}
         self._limit = limit
+        self._lock = threading.Lock()
 
     def get(self, device: torch.device, raw: bytes) -> torch.Tensor:
         key = (device.index, raw)
-        t = self._d.pop(key, None)
-        if t is None:
-            t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        with self._lock:
+            t = self._d.pop(key, None)
+        if t is None:   # uploaded outside the lock (it synchronises a stream); two threads racing for the same new
+            t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)   # content both upload it, the later entry stays
             if not torch.cuda.is_current_stream_capturing():
                 torch.cuda.current_stream(device).synchronize()
-        self._d[key] = t
-        while len(self._d) > self._limit:
-            self._d.pop(next(iter(self._d)))
+        with self._lock:
+            self._d[key] = t
+            while len(self._d) > self._limit:
+                self._d.pop(next(iter(self._d)))
         return t
 
 
