@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LMI_VERSION 100 /* 0.1.0 */
+#define LMI_VERSION 101 /* 0.1.1: lmi_finalize_args grew the keypoint fields */
 
 enum lmi_status {
   LMI_OK = 0,
@@ -206,6 +206,11 @@ typedef struct lmi_finalize_args {
   int32_t *mask_slot;              /* [device] int32 (batch, max_det), may be NULL */
   int32_t *slot_map;               /* [device] int32 (batch*max_det), may be NULL */
   int32_t *slot_base;              /* [device] int32 (batch+1), may be NULL */
+  /* Keypoint models (`Yolov8Pose.postprocess`, object_detectors/yolov8_lmi/model.py:568-569): kpt_n > 0 also runs
+   * `ops.scale_coords` -- lmi_scale_coords, same arithmetic -- on the row columns kpt_col0 .. kpt_col0 + kpt_n * kpt_ndim
+   * (kpt_ndim 2 or 3: x, y [, visibility]) while the rows are written.  0: none. */
+  int32_t kpt_col0, kpt_n, kpt_ndim;
+  int32_t reserved2;
 } lmi_finalize_args;
 int lmi_nms_v8_ex(const void *pred, int pred_dtype, int batch, int nc, int nm, int anchors, float conf_thres,
                   double iou_thres, int agnostic, int max_det, int max_nms, float max_wh, int rotated,

@@ -31,7 +31,8 @@ class lmi_finalize_args(C.Structure):
     _fields_ = [("model_h", C.c_int32), ("model_w", C.c_int32), ("uniform_h0", C.c_int32), ("uniform_w0", C.c_int32),
                 ("orig_hw", C.c_void_p), ("pad_round", C.c_int32), ("reserved", C.c_int32), ("thres", C.c_void_p),
                 ("uniform_thres", C.c_double), ("keep", C.c_void_p), ("keep_count", C.c_void_p), ("mask_slot", C.c_void_p),
-                ("slot_map", C.c_void_p), ("slot_base", C.c_void_p)]
+                ("slot_map", C.c_void_p), ("slot_base", C.c_void_p),
+                ("kpt_col0", C.c_int32), ("kpt_n", C.c_int32), ("kpt_ndim", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class lmi_mask_image(C.Structure):

@@ -751,6 +751,7 @@ struct FinalizeParams {
   int *mask_slot;
   int *slot_map;
   int *slot_base;
+  int kpt_col0, kpt_n, kpt_ndim;   // fused form only: keypoint columns of the rows (kpt_n = 0: none)
 };
 
 // Python round(): nearest, ties to even
@@ -848,7 +849,18 @@ __device__ __forceinline__ void emit_rows(const SortNmsParams &S, int b, int K, 
   const int row = 6 + S.nm;
   float *od = S.out_det + (size_t)b * S.max_det * row;
   BoxScale bs{};
-  if (S.fin) bs = box_scale(S.F, b);
+  float kpx = 0.0f, kpy = 0.0f;   // ops.scale_coords on the keypoint columns: the pads are NOT rounded, unlike scale_boxes'
+  const int k0 = S.fin ? S.F.kpt_col0 : 0, k1 = (S.fin && S.F.kpt_n > 0) ? k0 + S.F.kpt_n * S.F.kpt_ndim : 0;
+  if (S.fin) {
+    bs = box_scale(S.F, b);
+    if (k1 > 0) {
+      const int h0 = S.F.orig_hw ? S.F.orig_hw[2 * b] : S.F.uh0, w0 = S.F.orig_hw ? S.F.orig_hw[2 * b + 1] : S.F.uw0;
+      const double gh = (double)S.F.model_h / (double)h0, gw = (double)S.F.model_w / (double)w0;
+      const double gain = gh < gw ? gh : gw;
+      kpx = (float)(((double)S.F.model_w - (double)w0 * gain) / 2.0);
+      kpy = (float)(((double)S.F.model_h - (double)h0 * gain) / 2.0);
+    }
+  }
   for (int e = tid; e < K * row; e += kSortThreads) {
     const int t = e / row, col = e - t * row;
     const uint64_t key = keys[kpos[t]];
@@ -865,6 +877,11 @@ __device__ __forceinline__ void emit_rows(const SortNmsParams &S, int b, int K, 
       v = (float)S.cls_of[(size_t)b * A + anchor];
     } else {
       v = ldf(pb, (size_t)(4 + S.nc + (col - 6)) * A + anchor);
+      if (col >= k0 && col < k1) {   // scale_coords_kernel's arithmetic: (p - pad) / gain, clipped to the original frame
+        const int d = (col - k0) % S.F.kpt_ndim;
+        if (d == 0) v = fminf(fmaxf((v - kpx) / bs.gain, 0.0f), bs.w0);
+        else if (d == 1) v = fminf(fmaxf((v - kpy) / bs.gain, 0.0f), bs.h0);
+      }
     }
     od[e] = v;
     if (col == 0) S.out_anchor[(size_t)b * S.max_det + t] = (int)anchor;
@@ -1955,8 +1972,12 @@ static int nms_check_suppress(const float *out_det, const int32_t *out_count, co
   return LMI_OK;
 }
 
-static int fin_check(const lmi_finalize_args *fin, int batch, int rotated) {
+static int fin_check(const lmi_finalize_args *fin, int batch, int rotated, int nm) {
   if (fin == nullptr) return LMI_OK;
+  LMI_REQUIRE(fin->kpt_n >= 0 && (fin->kpt_n == 0 || ((fin->kpt_ndim == 2 || fin->kpt_ndim == 3) && fin->kpt_col0 >= 6 &&
+                                                       fin->kpt_col0 + fin->kpt_n * fin->kpt_ndim <= 6 + nm)),
+              LMI_ERR_BAD_ARG, "lmi_nms_v8_ex: finalize: keypoint columns %d + %d x %d do not fit rows of %d", fin->kpt_col0, fin->kpt_n,
+              fin->kpt_ndim, 6 + nm);
   LMI_REQUIRE(!rotated, LMI_ERR_BAD_ARG, "lmi_nms_v8_ex: the fused finalize serves axis-aligned boxes only (use lmi_finalize_obb)");
   LMI_REQUIRE(fin->keep && fin->keep_count, LMI_ERR_BAD_ARG, "lmi_nms_v8_ex: finalize: NULL pointer");
   LMI_REQUIRE(batch <= 8192, LMI_ERR_BAD_ARG, "lmi_nms_v8_ex: finalize: batch %d > 8192", batch);
@@ -1988,6 +2009,7 @@ static void fin_params(const lmi_finalize_args *fin, float *det, const int32_t *
   F.model_h = fin->model_h; F.model_w = fin->model_w; F.orig_hw = fin->orig_hw; F.uh0 = fin->uniform_h0; F.uw0 = fin->uniform_w0;
   F.pad_round = fin->pad_round ? 1 : 0; F.thres = fin->thres; F.uniform_thres = fin->uniform_thres; F.keep = fin->keep;
   F.keep_count = fin->keep_count; F.mask_slot = fin->mask_slot; F.slot_map = fin->slot_map; F.slot_base = fin->slot_base;
+  F.kpt_col0 = fin->kpt_col0; F.kpt_n = fin->kpt_n; F.kpt_ndim = fin->kpt_ndim;
 }
 
 // second half: sort + suppression (+ the fused finalize), one workgroup per image (latency / LDS-bound, next to no HBM traffic)
@@ -2086,7 +2108,7 @@ int lmi_nms_suppress_ex(const void *pred, int pred_dtype, int batch, int nc, int
   if (rc) return rc;
   rc = nms_check_suppress(out_det, out_count, out_anchor, iou_thres, max_det, max_nms);
   if (rc) return rc;
-  rc = fin_check(fin, batch, rotated & 0xff);
+  rc = fin_check(fin, batch, rotated & 0xff, nm);
   if (rc) return rc;
   return nms_suppress(C, pred, batch, nc, nm, anchors, iou_thres, agnostic, max_det, max_nms, max_wh, out_det, out_count, out_anchor,
                       rotated, fin);
@@ -2100,7 +2122,7 @@ int lmi_nms_v8_ex(const void *pred, int pred_dtype, int batch, int nc, int nm, i
   if (rc) return rc;
   rc = nms_check_suppress(out_det, out_count, out_anchor, iou_thres, max_det, max_nms);
   if (rc) return rc;
-  rc = fin_check(fin, batch, rotated & 0xff);
+  rc = fin_check(fin, batch, rotated & 0xff, nm);
   if (rc) return rc;
   rc = nms_decode(C, pred, batch, nc, nm, anchors, conf_thres);
   if (rc) return rc;
@@ -2166,6 +2188,7 @@ int lmi_finalize_detections(float *det, const int32_t *count, int batch, int max
   F.model_h = model_h; F.model_w = model_w; F.orig_hw = orig_hw; F.uh0 = uniform_h0; F.uw0 = uniform_w0;
   F.pad_round = pad_round ? 1 : 0; F.thres = thres; F.uniform_thres = uniform_thres; F.keep = keep; F.keep_count = keep_count;
   F.mask_slot = mask_slot; F.slot_map = slot_map; F.slot_base = slot_base;
+  F.kpt_col0 = 0; F.kpt_n = 0; F.kpt_ndim = 0;
   LMI_REQUIRE(max_det <= LMI_MAX_DET_CAP, LMI_ERR_LIMIT, "lmi_finalize_detections: max_det %d > %d", max_det, LMI_MAX_DET_CAP);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(finalize_boxes_kernel, dim3(batch), dim3((max_det + 63) / 64 * 64), 0, s, F);

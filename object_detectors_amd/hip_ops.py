@@ -252,7 +252,7 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
     return out, ops
 
 
-def _finalize_setup(b: int, max_det: int, nc: int, dev, model_hw, orig_hw, thres, pad_round: bool, with_slots: bool, out):
+def _finalize_setup(b: int, max_det: int, nc: int, dev, model_hw, orig_hw, thres, pad_round: bool, with_slots: bool, out, kpt=None):
     """Buffers + the lmi_finalize_args record shared by finalize_detections and the fused nms_v8(finalize=...).
     Returns (result dict, args struct, tensors to keep alive until the call is enqueued)."""
     if out is not None:   # reuse a previous result dict of the same shapes
@@ -287,7 +287,8 @@ def _finalize_setup(b: int, max_det: int, nc: int, dev, model_hw, orig_hw, thres
         th_ptr, ut = None, float(thres)
     p = lambda t: t.data_ptr() if t is not None else None
     args = _lib.lmi_finalize_args(int(model_hw[0]), int(model_hw[1]), uh, uw, ohw_ptr, int(bool(pad_round)), 0, th_ptr, ut,
-                                  keep.data_ptr(), keep_count.data_ptr(), p(mask_slot), p(slot_map), p(slot_base))
+                                  keep.data_ptr(), keep_count.data_ptr(), p(mask_slot), p(slot_map), p(slot_base),
+                                  *((int(kpt[0]), int(kpt[1]), int(kpt[2]), 0) if kpt else (0, 0, 0, 0)))
     res = {"keep": keep, "keep_count": keep_count, "mask_slot": mask_slot, "slot_map": slot_map, "slot_base": slot_base}
     return res, args, alive
 
@@ -301,7 +302,8 @@ def nms_v8(pred: torch.Tensor, conf_thres: float, iou_thres: float = 0.45, agnos
     decode_done: an event recorded on the current stream between the candidate filter (HBM-bound) and the
     sort + suppression pass (latency-bound): work on another stream that waits for it shares the chip with the
     latter (lmi_nms_decode_ex / lmi_nms_suppress_ex instead of the one-call lmi_nms_v8_ex; same result).
-    finalize: dict(model_hw=, orig_hw=, thres=[, pad_round=True, with_slots=True, out=None]) -- the arguments of
+    finalize: dict(model_hw=, orig_hw=, thres=[, pad_round=True, with_slots=True, out=None, kpt=(col0, nkpt, ndim)]) -- kpt:
+    keypoint models, `scale_coords` on those row columns in the same launch (`Yolov8Pose.postprocess`); otherwise the arguments of
     finalize_detections: scale_boxes + clip, class threshold and survivor ranks then run in the suppression kernel's
     epilogue (one launch less, same results) and the call returns a 4th value, finalize_detections' result dict.
 
@@ -340,7 +342,8 @@ def nms_v8(pred: torch.Tensor, conf_thres: float, iou_thres: float = 0.45, agnos
         if rotated:
             raise ValueError("nms_v8: finalize= serves axis-aligned boxes (use finalize_obb for rotated ones)")
         fin_res, fin_args, alive = _finalize_setup(b, max_det, nc, dev, finalize["model_hw"], finalize["orig_hw"], finalize["thres"],
-                                                   finalize.get("pad_round", True), finalize.get("with_slots", True), finalize.get("out"))
+                                                   finalize.get("pad_round", True), finalize.get("with_slots", True), finalize.get("out"),
+                                                   finalize.get("kpt"))
         fin_ptr = C.addressof(fin_args)
     nbytes = int(_L.lmi_nms_workspace_bytes(b, a))
     ws = _ws.get(dev, "nms", nbytes)

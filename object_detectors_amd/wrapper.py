@@ -485,9 +485,10 @@ class Yolov8PoseCore(Yolov8Core):
         model_hw = tuple(img.shape[2:])
         shapes = [tuple((orig_imgs[i] if isinstance(orig_imgs, list) else orig_imgs).shape[:2]) for i in range(B)]
         ohw = shapes[0] if all(s == shapes[0] for s in shapes) else torch.tensor(shapes, dtype=torch.int32, device=self.device)
-        det, count, _ = ops.nms_v8(preds, float(conf2), float(iou), agnostic=bool(agnostic), max_det=int(max_det), nc=nc)
-        fin = ops.finalize_detections(det, count, nc, model_hw, ohw, thres, with_slots=False)
-        ops.scale_coords(det, count, nkpt, ndim, model_hw, ohw)
+        # ONE launch chain, like det / seg: scale_boxes + clip, the class threshold and scale_coords on the keypoint columns
+        # run in the suppression kernel's epilogue (reference: three passes over the rows, model.py:555-569)
+        det, count, _, fin = ops.nms_v8(preds, float(conf2), float(iou), agnostic=bool(agnostic), max_det=int(max_det), nc=nc,
+                                        finalize=dict(model_hw=model_hw, orig_hw=ohw, thres=thres, with_slots=False, kpt=(6, nkpt, ndim)))
         count_h, keep_h, det_h = self._to_host([count, fin["keep"], det])   # pinned, asynchronous, ONE synchronisation
         keep_h = keep_h.astype(bool)
         results = collections.defaultdict(list)

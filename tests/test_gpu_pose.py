@@ -88,3 +88,33 @@ def test_pose_predict_against_oracle(pose):
         assert set(tinfo) == {'preproc', 'proc', 'postproc'}
     none, _ = pose.predict(frame, 0.9999999, operators=operators)
     assert len(none['boxes']) == 0 and len(none['points']) == 0
+
+
+@pytest.mark.parametrize("ndim,ragged,agnostic", [(3, False, False), (2, True, False), (3, True, True)])
+def test_fused_keypoint_epilogue_equals_the_three_calls(ndim, ragged, agnostic):
+    """`Yolov8Pose.postprocess` as ONE launch chain (nms_v8(finalize=dict(..., kpt=...))) against nms_v8 +
+    finalize_detections + scale_coords (reference: object_detectors/yolov8_lmi/model.py:555-569) -- rows bit-equal,
+    per-class thresholds, uniform and ragged original sizes, and against the oracle's scale_coords."""
+    from object_detectors_amd import hip_ops as ops
+    rng = np.random.default_rng(17 + ndim)
+    B, nc, nk, S = 4, 3, 17, 320
+    p = synth.head(rng, B, nc, nk * ndim, S, objects=12)
+    p[:, 4 + nc:] = rng.uniform(-30, S + 30, (B, nk * ndim, p.shape[2])).astype(F32)
+    x = torch.from_numpy(p).cuda()
+    shapes = [(270, 480), (375, 500), (1080, 1920), (200, 90)] if ragged else [(270, 480)] * B
+    ohw = torch.tensor(shapes, dtype=torch.int32).cuda() if ragged else shapes[0]
+    thres = torch.tensor([0.3, 0.5, 0.26], dtype=torch.float64).cuda()
+    det, count, anchor = ops.nms_v8(x, 0.25, 0.45, nc=nc, agnostic=agnostic)
+    raw = det.clone()
+    fin = ops.finalize_detections(det, count, nc, (S, S), ohw, thres, with_slots=False)
+    ops.scale_coords(det, count, nk, ndim, (S, S), ohw)
+    d2, c2, a2, f2 = ops.nms_v8(x, 0.25, 0.45, nc=nc, agnostic=agnostic,
+                                finalize=dict(model_hw=(S, S), orig_hw=ohw, thres=thres, with_slots=False, kpt=(6, nk, ndim)))
+    torch.cuda.synchronize()
+    assert torch.equal(count, c2) and torch.equal(fin["keep_count"], f2["keep_count"]) and int(count.sum()) > 0
+    for b, n in enumerate(count.tolist()):
+        assert torch.equal(det[b, :n], d2[b, :n]) and torch.equal(anchor[b, :n], a2[b, :n]) and torch.equal(fin["keep"][b, :n], f2["keep"][b, :n]), b
+        ref = OB.scale_coords((S, S), raw[b, :n, 6:].cpu().numpy().reshape(n, nk, ndim), shapes[b] + (3,))
+        assert np.array_equal(d2[b, :n, 6:].cpu().numpy().reshape(n, nk, ndim), ref), b
+    with pytest.raises(ValueError):
+        ops.nms_v8(x, 0.25, 0.45, nc=nc, finalize=dict(model_hw=(S, S), orig_hw=ohw, thres=thres, with_slots=False, kpt=(6, nk + 1, ndim)))
