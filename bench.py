@@ -303,7 +303,7 @@ def launch_ranks(n: int, argv) -> int:
     The parent only counts devices (which does not initialise the GPU) and forwards the child's return code."""
     import subprocess
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and not os.environ.get("LMI_BENCH_SHARE_DEVICE"):
         log(f"[bench] --gpus {n} but only {have} GPU(s) visible")
         return 2
     env = dict(os.environ)
@@ -355,13 +355,22 @@ def main():
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run for N>1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # LMI_BENCH_SHARE_DEVICE=1: a rehearsal of the N-rank launch on a box with fewer GPUs -- every rank runs on cuda:0 and
+    # the end-of-run gather goes over gloo (RCCL refuses two ranks on one device).  Its numbers mean nothing (the ranks
+    # share one GPU); it proves the launcher, the sharding and the gather.  The line says so in config.sharding.
+    share = bool(os.environ.get("LMI_BENCH_SHARE_DEVICE"))
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    gather_dev = None if share else device
     dist = None
     if world > 1 or os.environ.get("LMI_BENCH_FORCE_DIST"):   # the variable: a one-rank rehearsal of the multi-GPU path on a one-GPU box
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from object_detectors_amd import shard
     cfg = WORKLOADS[args.workload]
@@ -441,7 +450,7 @@ def main():
         barrier()
         block_s.append(time.perf_counter() - t0)
     # max over ranks per block, then the median block
-    block_all = shard.gather_vector(torch.tensor(block_s, dtype=torch.float64), device=device)
+    block_all = shard.gather_vector(torch.tensor(block_s, dtype=torch.float64), device=gather_dev)
     per_block = torch.stack(block_all).max(dim=0).values
     elapsed = float(per_block.median())
 
@@ -480,7 +489,7 @@ def main():
     chk = sum(chks) % (2 ** 61 - 1)
     # the only communication of the run: per-shard counters gathered over RCCL (backend nccl) for the report
     reports = shard.gather_report({"images": B * steps, "survivors": n_surv_total, "kept": sum(k * n for k, n in zip(kept, steps_per_entry)),
-                                   "chk_hi": chk >> 31, "chk_lo": chk & (2 ** 31 - 1)}, device=device)
+                                   "chk_hi": chk >> 31, "chk_lo": chk & (2 ** 31 - 1)}, device=gather_dev)
     total_images = int(sum(r["images"] for r in reports))
     value = total_images / elapsed
 
@@ -571,7 +580,8 @@ def main():
                        "replay_equals_eager": replay_ok,
                        "step_overlap": ("letterbox stream joined once per block: step k+1's candidate filter may run beside step k's letterbox"
                                         if (block_graph is not None and args.pipeline_steps and fork and not cfg["nm"]) else "none: every step joins its streams"),
-                       "sharding": f"{world} x independent batches, no collective on the hot path"},
+                       "sharding": f"{world} x independent batches, no collective on the hot path"
+                                   + (" -- REHEARSAL: all ranks share cuda:0 (LMI_BENCH_SHARE_DEVICE), the value is not a multi-GPU number" if share else "")},
             "roofline": roof, "cpu_baseline": cpu, "nms": nms_t, "letterbox": lb_t,
         }
         print(json.dumps(res), flush=True)

@@ -20,11 +20,14 @@ def run_both(L, ops, check, head, conf, iou, nc, agnostic, max_det=300):
     count = torch.full((b,), -1, dtype=torch.int32, device="cuda")
     anchor = torch.full((b, max_det), -1, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated()
+    # "allocates nothing", pinned at the driver: torch's own counter only sees torch's caching allocator, a hipMalloc
+    # inside the library would not move it.  The per-device set-up (LDS limits, the array's address) ran with the
+    # reference call above.
+    before, free_before = torch.cuda.memory_allocated(), torch.cuda.mem_get_info()[0]
     check(L.lmi_nms_v8_static(pred.data_ptr(), b, nc, nm, a, conf, iou, int(agnostic), max_det, 30000, 7680.0,
                               det.data_ptr(), count.data_ptr(), anchor.data_ptr(), torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
-    assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.memory_allocated() == before and torch.cuda.mem_get_info()[0] == free_before
     rc, c = ref_count.cpu().numpy(), count.cpu().numpy()
     assert np.array_equal(rc, c) and c.sum() > 0
     for i in range(b):
@@ -46,6 +49,23 @@ def test_nms_static_matches_nms_v8_on_consecutive_calls():
     n3 = run_both(L, ops, _lib.check, dense, 0.25, 0.6, 80, True)                 # agnostic path, larger again
     n4 = run_both(L, ops, _lib.check, big, 0.3, 0.45, 80, False, max_det=20)
     assert n1 > n2 > 0 and n3 > 0 and n4 == 80
+    # under HIP graph capture, where an allocation is an error: captured once, replayed on fresh contents
+    pred = torch.from_numpy(small).cuda()
+    ref = ops.nms_v8(pred, 0.25, 0.45, nc=80)
+    det = torch.empty((2, 300, 38), dtype=torch.float32, device="cuda")
+    count = torch.empty((2,), dtype=torch.int32, device="cuda")
+    anchor = torch.empty((2, 300), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        _lib.check(L.lmi_nms_v8_static(pred.data_ptr(), 2, 80, 32, 2100, 0.25, 0.45, 0, 300, 30000, 7680.0, det.data_ptr(),
+                                       count.data_ptr(), anchor.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    det.fill_(-1.0); count.fill_(-1)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(count, ref[1])
+    for i, n in enumerate(count.tolist()):
+        assert torch.equal(det[i, :n], ref[0][i, :n]) and torch.equal(anchor[i, :n], ref[2][i, :n])
     # beyond the built-in workspace: rejected before anything is launched
     pred = torch.zeros((12, 84, 8400), device="cuda")
     out = torch.zeros((12, 300, 6), device="cuda")
