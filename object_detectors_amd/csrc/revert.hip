@@ -13,6 +13,9 @@
 //  revert_masks_kernel<T>    one stage = [centred crop / zero pad] -> [bilinear resize] -> [flip], fused: the crop
 //                            and pad are index arithmetic on the resize taps, the flip mirrors the store address.
 //                            16 bytes per lane per store; write-bound when it enlarges (640x360 -> 1920x1080).
+//  revert_resize_kernel<T>   the resize stage with the source rows staged in LDS (outputs with dh + dw > 128).
+//  revert_resize_lines_kernel  the same for fp32 rows that are not whole 128-byte lines: results through LDS, stores
+//                            cut by absolute address.
 #include "common.h"
 
 namespace {
@@ -185,6 +188,41 @@ __global__ __launch_bounds__(256) void revert_masks_kernel(MaskStage S) {
   }
 }
 
+// The virtual source rows the output rows [ra, rb) read, staged in LDS as fp32 (crop offset and zero pad folded in, a
+// repeat of the last column so that the right-hand tap is always the next float); returns the first staged row.
+// Ends with a workgroup barrier.
+template <typename T>
+__device__ __forceinline__ int stage_source_rows(const MaskStage &S, const T *src, int ra, int rb, float *L, int ls) {
+  constexpr int N = Px<T>::N;
+  const float scale_h = (float)S.vh / (float)S.dh;
+  int i0, i1, j0, j1; float l0, l1;
+  bilinear_src(scale_h, ra, S.vh, i0, i1, l0, l1);
+  const int vy_first = i0;
+  bilinear_src(scale_h, rb - 1, S.vh, j0, j1, l0, l1);
+  const int nrows = j1 - vy_first + 1;   // fits the LDS buffer by the host's choice of rows_per_block
+  // groups of N source pixels: one 16-byte load (at whatever address) where the group lies inside the source,
+  // pixel by pixel at the pad border and for the repeated last column
+  const int groups = (ls + N - 1) / N;
+  for (int idx = threadIdx.x; idx < nrows * groups; idx += blockDim.x) {
+    const int r = idx / groups, c0 = (idx - r * groups) * N;
+    const int sy = vy_first + r + S.oy, sx0 = c0 + S.ox;
+    float *d = L + r * ls + c0;
+    if (sy >= 0 && sy < S.sh && sx0 >= 0 && sx0 + N <= S.sw && c0 + N <= S.vw) {
+      float f[N];
+      Px<T>::load_group(src + (size_t)sy * S.sw + sx0, f);
+#pragma unroll
+      for (int k = 0; k < N; k += 4) *reinterpret_cast<float4 *>(d + k) = make_float4(f[k], f[k + 1], f[k + 2], f[k + 3]);
+    } else {
+      for (int k = 0; k < N && c0 + k < ls; ++k) {
+        const int sx = min(c0 + k, S.vw - 1) + S.ox;
+        d[k] = (sy >= 0 && sy < S.sh && sx >= 0 && sx < S.sw) ? Px<T>::load(src + (size_t)sy * S.sw + sx) : 0.0f;
+      }
+    }
+  }
+  __syncthreads();
+  return vy_first;
+}
+
 // The resize stage for outputs with dh + dw > 128 (aten's separable kernel), in the structure of mask_box_kernel:
 // grid (strips of rows_per_block output rows, masks).  A workgroup stages the virtual source rows its strip reads
 // (crop offset and zero pad folded in, converted to fp32, plus a repeat of the last column so that the right-hand tap
@@ -203,34 +241,7 @@ __global__ __launch_bounds__(256) void revert_resize_kernel(MaskStage S, int row
   T *dst = reinterpret_cast<T *>(S.dst) + (size_t)mi * S.dh * S.dw;
   const float scale_h = (float)S.vh / (float)S.dh, scale_w = (float)S.vw / (float)S.dw;
   const int ls = (S.vw + 1 + 3) & ~3;   // staged row: vw columns + a repeat of the last, padded to whole 16-byte groups
-  int vy_first;
-  {
-    int i0, i1, j0, j1; float l0, l1;
-    bilinear_src(scale_h, ra, S.vh, i0, i1, l0, l1);
-    vy_first = i0;
-    bilinear_src(scale_h, rb - 1, S.vh, j0, j1, l0, l1);
-    const int nrows = j1 - vy_first + 1;   // fits the LDS buffer by the host's choice of rows_per_block
-    // groups of N source pixels: one 16-byte load (at whatever address) where the group lies inside the source,
-    // pixel by pixel at the pad border and for the repeated last column
-    const int groups = (ls + N - 1) / N;
-    for (int idx = threadIdx.x; idx < nrows * groups; idx += 256) {
-      const int r = idx / groups, c0 = (idx - r * groups) * N;
-      const int sy = vy_first + r + S.oy, sx0 = c0 + S.ox;
-      float *d = L + r * ls + c0;
-      if (sy >= 0 && sy < S.sh && sx0 >= 0 && sx0 + N <= S.sw && c0 + N <= S.vw) {
-        float f[N];
-        Px<T>::load_group(src + (size_t)sy * S.sw + sx0, f);
-#pragma unroll
-        for (int k = 0; k < N; k += 4) *reinterpret_cast<float4 *>(d + k) = make_float4(f[k], f[k + 1], f[k + 2], f[k + 3]);
-      } else {
-        for (int k = 0; k < N && c0 + k < ls; ++k) {
-          const int sx = min(c0 + k, S.vw - 1) + S.ox;
-          d[k] = (sy >= 0 && sy < S.sh && sx >= 0 && sx < S.sw) ? Px<T>::load(src + (size_t)sy * S.sw + sx) : 0.0f;
-        }
-      }
-    }
-    __syncthreads();
-  }
+  const int vy_first = stage_source_rows<T>(S, src, ra, rb, L, ls);
   const int chunks = (S.dw + N - 1) / N;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lpr = min(chunks, 64);
@@ -300,6 +311,117 @@ __global__ __launch_bounds__(256) void revert_resize_kernel(MaskStage S, int row
         }
       }
     }
+  }
+}
+
+// fp32 outputs whose rows are not whole 128-byte lines (dw % 32 != 0: 1916, 1080, 500 ...).  A wave's 16-byte stores are
+// issued a quarter wave at a time; 16 lanes x 16 bytes that do not start on a line boundary touch three lines instead
+// of two, and every row starts at a different offset inside its line, so no fixed lane -> column assignment is aligned
+// (revert_resize_kernel on such rows: 1.5x the time of the aligned width next to it).  Here the arithmetic keeps the
+// fixed assignment -- a lane owns up to ITER chunk columns and walks down the rows, the horizontally interpolated
+// source-row pair staying in registers -- but the results of `rs` output rows go to LDS, laid out exactly as they lie
+// in memory (whole output rows are written, so these rows are ONE contiguous byte range of the mask's plane); then all
+// lanes copy that range out in 16-byte chunks cut by ABSOLUTE address, 8 lanes per 128-byte line.  The workgroup is `cl`
+// lanes (rounded up to whole waves), one per chunk column of the first ITER-th of the row.  200 masks 640x360 ->
+// 1080x1916: 495 -> 334 us (1080x1920 on revert_resize_kernel: 325); -> 1920x1080: 477 -> 366-420; 50 -> 2160x3836:
+// 501 -> 377-400.  Used where the stage is bound by its stores (lmi_revert_masks_stage has the rule).
+template <int ITER>
+__global__ __launch_bounds__(256) void revert_resize_lines_kernel(MaskStage S, int rows_per_block, int src_floats, int rs, int cl) {
+  constexpr int N = 4;
+  extern __shared__ __attribute__((aligned(16))) float L[];
+  const long long mi = blockIdx.y;
+  const int ra = blockIdx.x * rows_per_block, rb = min(ra + rows_per_block, S.dh);
+  if (ra >= rb) return;
+  const float *src = reinterpret_cast<const float *>(S.src) + (size_t)mi * S.sh * S.sw;
+  float *dst = reinterpret_cast<float *>(S.dst) + (size_t)mi * S.dh * S.dw;
+  const float scale_h = (float)S.vh / (float)S.dh, scale_w = (float)S.vw / (float)S.dw;
+  const int ls = (S.vw + 1 + 3) & ~3;
+  const int vy_first = stage_source_rows<float>(S, src, ra, rb, L, ls);
+  float *Lout = L + src_floats;
+
+  const int tid = threadIdx.x;
+  const int c = tid;                               // column lane (the workgroup is cl lanes rounded up to whole waves)
+  const bool active = c < cl;
+  const int chunks = (S.dw + N - 1) / N;
+  const bool vec = (S.dw & 3) == 0;                // chunks are whole and 16-byte aligned inside Lout
+  int oa[ITER][N];
+  float wa[ITER][N], wb[ITER][N], tu[ITER][N], tl[ITER][N];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int x0 = (c + it * cl) * N;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      int ia, ib;
+      bilinear_src(scale_w, min(x0 + k, S.dw - 1), S.vw, ia, ib, wa[it][k], wb[it][k]);
+      oa[it][k] = ia * 4;
+      tu[it][k] = 0.0f; tl[it][k] = 0.0f;
+    }
+  }
+  typedef float taps __attribute__((ext_vector_type(2), aligned(4)));
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef f4 f4_a4 __attribute__((aligned(4)));
+  int cur0 = -1, cur1 = -1;
+  const uintptr_t base = reinterpret_cast<uintptr_t>(dst);
+  for (int ys = ra; ys < rb; ys += rs) {
+    const int ye = min(ys + rs, rb);
+    if (active) {
+      for (int y = ys; y < ye; ++y) {
+        int iy0, iy1; float ly0, ly1;
+        bilinear_src(scale_h, y, S.vh, iy0, iy1, ly0, ly1);
+        const bool fresh = iy0 != cur0 || iy1 != cur1, shift = iy0 == cur1, same = iy1 == iy0;
+        const float *r0 = L + (iy0 - vy_first) * ls, *r1 = L + (iy1 - vy_first) * ls;
+        // memory order of the sub-strip: rows [ys, ye), or their mirror images [dh - ye, dh - ys)
+        const int lrow = S.flip_ud ? ye - 1 - y : y - ys;
+        float *orow = Lout + (size_t)lrow * S.dw;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+          const int chunk = c + it * cl;
+          if (chunk >= chunks) continue;
+          const int x0 = chunk * N;
+          if (fresh) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+              if (shift) tu[it][k] = tl[it][k];
+              else {
+                const taps a = *reinterpret_cast<const taps *>(reinterpret_cast<const char *>(r0) + oa[it][k]);
+                tu[it][k] = fmaf(a.x, wa[it][k], a.y * wb[it][k]);
+              }
+              if (same) tl[it][k] = tu[it][k];
+              else {
+                const taps a = *reinterpret_cast<const taps *>(reinterpret_cast<const char *>(r1) + oa[it][k]);
+                tl[it][k] = fmaf(a.x, wa[it][k], a.y * wb[it][k]);
+              }
+            }
+          }
+          float v[N];
+#pragma unroll
+          for (int k = 0; k < N; ++k) v[k] = fmaf(tu[it][k], ly0, tl[it][k] * ly1);
+          if (vec) {
+            if (!S.flip_lr) *reinterpret_cast<f4 *>(orow + x0) = f4{v[0], v[1], v[2], v[3]};
+            else *reinterpret_cast<f4 *>(orow + (S.dw - x0 - N)) = f4{v[3], v[2], v[1], v[0]};
+          } else {
+            for (int k = 0; k < N && x0 + k < S.dw; ++k) orow[S.flip_lr ? S.dw - 1 - (x0 + k) : x0 + k] = v[k];
+          }
+        }
+        cur0 = iy0; cur1 = iy1;
+      }
+    }
+    __syncthreads();
+    // copy-out: floats [ga, ga + cnt) of the plane
+    const long long ga = (long long)(S.flip_ud ? S.dh - ye : ys) * S.dw;
+    const int cnt = (ye - ys) * S.dw;
+    const uintptr_t a0 = base + (uintptr_t)ga * 4, a1 = a0 + (uintptr_t)cnt * 4;
+    for (uintptr_t addr = (a0 & ~(uintptr_t)127) + (uintptr_t)tid * 16; addr < a1; addr += (uintptr_t)blockDim.x * 16) {
+      const int idx = (int)(((long long)addr - (long long)a0) / 4);   // first float of the chunk inside Lout; a0 and addr are both multiples of 4
+      if (idx >= 0 && idx + N <= cnt) {
+        const f4 o = *reinterpret_cast<const f4_a4 *>(Lout + idx);
+        __builtin_nontemporal_store(o, reinterpret_cast<f4 *>(addr));
+      } else {
+        for (int k = 0; k < N; ++k)
+          if (idx + k >= 0 && idx + k < cnt) reinterpret_cast<float *>(addr)[k] = Lout[idx + k];
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -509,6 +631,43 @@ int lmi_revert_masks_stage(const void *src, int dtype, int64_t m, int src_h, int
   dim3 grid(((S.dw + n - 1) / n + 63) / 64, (S.dh + 3) / 4, (unsigned)m);
   LMI_REQUIRE(grid.y <= 65535, LMI_ERR_LIMIT, "lmi_revert_masks_stage: output height %d too large", S.dh);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // fp32 rows that are not whole 128-byte lines, enlarged >= 6x in area (where the stage is bound by its stores; below
+  // that, and on narrow outputs, the extra pass through LDS costs what the aligned stores save: 720p 514 vs 496 us per
+  // 400 masks, measured): revert_resize_lines_kernel
+  if (S.resize && S.dh + S.dw > 128 && dtype == LMI_F32 && (S.dw & 31) != 0 && S.dw >= 512 &&
+      (long long)S.dh * S.dw >= 6LL * S.vh * S.vw) {
+    // a lane owns `it` chunk columns: the fewest that make a workgroup of <= 256 lanes cover a row
+    const int chunks = (S.dw + 3) / 4;
+    const int src_kb = 16, out_kb = 16;
+    int it = 0, cl = 0;
+    for (int i = 1; i <= 4 && it == 0; ++i) {
+      const int c = (chunks + i - 1) / i;
+      if (c <= 256) { it = i; cl = c; }
+    }
+    if (it > 0) {
+      const int lanes = (cl + 63) & ~63;
+      int rpb = 64, lds_rows = 0;
+      for (;; --rpb) {
+        lds_rows = (int)((double)rpb * S.vh / S.dh) + 3;
+        if (lds_rows > S.vh) lds_rows = S.vh;
+        if ((size_t)lds_rows * ((S.vw + 4) & ~3) * sizeof(float) <= (size_t)src_kb * 1024 || rpb == 1) break;
+      }
+      const size_t src_floats = (size_t)lds_rows * ((S.vw + 4) & ~3);
+      int rs = (out_kb * 1024) / (S.dw * 4);
+      if (rs > rpb) rs = rpb;
+      if (rs >= 1 && src_floats * 4 <= (size_t)src_kb * 1024) {
+        const size_t lds = src_floats * 4 + (size_t)rs * S.dw * 4 + 16;
+        dim3 g2((S.dh + rpb - 1) / rpb, (unsigned)m);
+        switch (it) {
+          case 1: hipLaunchKernelGGL(revert_resize_lines_kernel<1>, g2, dim3(lanes), lds, s, S, rpb, (int)src_floats, rs, cl); break;
+          case 2: hipLaunchKernelGGL(revert_resize_lines_kernel<2>, g2, dim3(lanes), lds, s, S, rpb, (int)src_floats, rs, cl); break;
+          case 3: hipLaunchKernelGGL(revert_resize_lines_kernel<3>, g2, dim3(lanes), lds, s, S, rpb, (int)src_floats, rs, cl); break;
+          default: hipLaunchKernelGGL(revert_resize_lines_kernel<4>, g2, dim3(lanes), lds, s, S, rpb, (int)src_floats, rs, cl); break;
+        }
+        return lmi_check_launch("revert_resize_lines_kernel");
+      }
+    }
+  }
   if (S.resize && S.dh + S.dw > 128) {
     // rows per strip: the largest power of two <= 64 whose staged source rows fit 48 KiB of LDS
     int rpb = 64, lds_rows = 0;

@@ -95,3 +95,42 @@ def test_revert_masks_letterbox_undo_1080p(ops, dtype):
     with pytest.raises(ValueError):
         ops.revert_masks(got[:1], [{"pad": [1000, 1000, 0, 0]}])
     assert ops.revert_masks(got[:0], oplist).shape == (0, 1080, 1920)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint8])
+@pytest.mark.parametrize("w,h,flip", [
+    (1916, 1080, None), (1080, 1920, (True, False)), (500, 375, (False, True)), (333, 250, (True, True)),
+    (36, 200, None), (100, 60, (True, False)), (4100, 300, None), (1000, 750, None), (2044, 500, (True, True)),
+    (1917, 1080, (True, False)), (2448, 2048, None), (3836, 600, (False, True)), (516, 1300, None),
+])
+def test_revert_masks_rows_that_are_not_whole_lines(ops, dtype, w, h, flip):
+    """Output rows that are not whole 128-byte lines (fp32: revert_resize_lines_kernel, results staged in LDS and
+    written out in chunks cut by absolute address), with the flips folded into the stage, every lane split the host
+    can choose (1-4 chunk columns per lane), widths that are not whole 16-byte chunks, a width beyond the kernel's
+    limit and shapes below its threshold (revert_resize_kernel): each mask equals the oracle bit for bit."""
+    rng = np.random.default_rng(w * 7 + h)
+    g = min(640 / h, 640 / w)
+    nw, nh = int(round(w * g)), int(round(h * g))
+    pl, pt = (640 - nw) // 2, (640 - nh) // 2
+    m = 5
+    src = np.zeros((m, 640, 640), dtype)
+    y, x = np.mgrid[0:640, 0:640]
+    for i in range(m):
+        cy, cx = rng.uniform(pt, pt + nh), rng.uniform(pl, pl + nw)
+        ry, rx = rng.uniform(5, nh / 2 + 5), rng.uniform(5, nw / 2 + 5)
+        inside = ((y - cy) / ry) ** 2 + ((x - cx) / rx) ** 2 < 1
+        src[i] = inside.astype(dtype) if dtype == np.uint8 else inside * rng.random((640, 640), dtype=np.float32)
+    oplist = [{"resize": [nw, nh, w, h]}, {"pad": [pl, 640 - nw - pl, pt, 640 - nh - pt]}]
+    if flip:
+        oplist.insert(0, {"flip": [flip[0], flip[1], w, h]})
+    got = ops.revert_masks(torch.from_numpy(src).cuda(), oplist)
+    assert got.shape == (m, h, w)
+    gc = got.cpu().numpy()
+    for i in range(m):
+        assert np.array_equal(gc[i], OG.revert_mask_to_origin(src[i], oplist)), i
+    # a plane that does not start on a 16-byte boundary (a view into a larger buffer, one float / byte further)
+    if dtype == np.float32:
+        big = torch.zeros(m * 640 * 640 + 1, dtype=torch.float32, device="cuda")
+        view = big[1:].view(m, 640, 640)
+        view.copy_(torch.from_numpy(src))
+        assert torch.equal(ops.revert_masks(view, oplist), got)
