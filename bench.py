@@ -470,7 +470,7 @@ def main():
         raise RuntimeError("bench: the timed replay's outputs differ from an eager pass over the same batch")
 
     # ---- per-kernel timing with HIP events on the stream each kernel runs on (eager passes, after the timed region) ----
-    n_ev = min(max(steps, 4), 40)
+    n_ev = 40   # the fill's duration varies by +-2.3 % from launch to launch (rocprof: 936-1070 us); 40 launches put the mean within 0.4 %
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
     lb_evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
     for k in range(n_ev):
@@ -502,7 +502,10 @@ def main():
         # logits rows x columns under each box read once) over the HIP-event time around both launches; in the
         # rocprof summary the averages of the listed kernels add up to avg_launch_ms (less the launch gap).
         kernel = "mask_zero_fill_kernel+mask_box_kernel<uint8>"
-        ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        ev_ms = [a.elapsed_time(b) for a, b in evs]
+        ms = float(np.mean(ev_ms))
+        if os.environ.get("LMI_BENCH_DEBUG_EVENTS"):
+            log("[bench] upsample event times (ms): " + " ".join(f"{t:.4f}" for t in ev_ms))
         algs = []
         for i in range(len(pool)):
             det, count, anchor, fin, masks = pipe.step(i, fork=False)
@@ -514,7 +517,8 @@ def main():
     else:
         from object_detectors_amd.roofline import letterbox_bytes
         kernel = "letterbox_tables_kernel+letterbox_kernel<float,128>"   # both launches of lmi_letterbox_u8_uniform sit between the events
-        ms = float(np.mean([a.elapsed_time(b) for a, b in lb_evs]))
+        ev_ms = [a.elapsed_time(b) for a, b in lb_evs]
+        ms = float(np.mean(ev_ms))
         alg = B * letterbox_bytes(H0, W0, S, S, 4)
     achieved = alg / (ms * 1e-3) / 1e9
     # HBM traffic per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
@@ -538,6 +542,7 @@ def main():
     del src, dst
     roof = {"kernel": kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_ms": round(ms, 4),
+            "launch_ms_min_median_max": [round(float(x), 4) for x in np.percentile(ev_ms, [0, 50, 100])],
             "algorithmic_bytes_per_launch": int(alg), "measured_copy_GBs": round(copy_gbs, 1),
             "frac_of_measured_copy": round(achieved / copy_gbs, 4), "frac_of_achievable_6300": round(achieved / 6300.0, 4)}
 

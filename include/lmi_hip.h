@@ -185,7 +185,7 @@ int lmi_nms_suppress(const float *pred, int batch, int nc, int nm, int anchors, 
  *               inf from class 9 on and the score threshold is rounded to fp16: deliberately not reproduced.)
  *   rotated     low byte != 0: oriented boxes (lmi_nms_v8_rotated); OR LMI_NMS_SWEEP_ONLY to keep the one-workgroup
  *               sorted sweep also where the suppressor-list kernel would run first (agnostic NMS or nc <= 8, and a
- *               batch that leaves every image >= 4 CUs: same result, for measurement and tests)
+ *               batch that leaves every image >= 16 CUs: same result, for measurement and tests)
  *   fin         NULL, or the arguments of lmi_finalize_detections (below): `ops.scale_boxes` + clip, the per-class
  *               threshold and the survivors' dense ranks (object_detectors/yolov8_lmi/model.py:222-232) then run in
  *               the suppression kernel's epilogue -- rows leave in original-image space and keep / keep_count are
