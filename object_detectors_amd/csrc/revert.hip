@@ -203,19 +203,38 @@ __device__ __forceinline__ int stage_source_rows(const MaskStage &S, const T *sr
   // groups of N source pixels: one 16-byte load (at whatever address) where the group lies inside the source,
   // pixel by pixel at the pad border and for the repeated last column
   const int groups = (ls + N - 1) / N;
-  for (int idx = threadIdx.x; idx < nrows * groups; idx += blockDim.x) {
-    const int r = idx / groups, c0 = (idx - r * groups) * N;
-    const int sy = vy_first + r + S.oy, sx0 = c0 + S.ox;
-    float *d = L + r * ls + c0;
-    if (sy >= 0 && sy < S.sh && sx0 >= 0 && sx0 + N <= S.sw && c0 + N <= S.vw) {
-      float f[N];
-      Px<T>::load_group(src + (size_t)sy * S.sw + sx0, f);
+  // four groups per lane and pass, their global loads issued before the first is converted: a strip's staging is a
+  // handful of passes, and one HBM round trip per pass was a third of a workgroup's lifetime
+  constexpr int U = 4;
+  const int total = nrows * groups;
+  for (int base = 0; base < total; base += U * (int)blockDim.x) {
+    float f[U][N];
+    bool vec[U];
+    int rr[U], cc[U];
 #pragma unroll
-      for (int k = 0; k < N; k += 4) *reinterpret_cast<float4 *>(d + k) = make_float4(f[k], f[k + 1], f[k + 2], f[k + 3]);
-    } else {
-      for (int k = 0; k < N && c0 + k < ls; ++k) {
-        const int sx = min(c0 + k, S.vw - 1) + S.ox;
-        d[k] = (sy >= 0 && sy < S.sh && sx >= 0 && sx < S.sw) ? Px<T>::load(src + (size_t)sy * S.sw + sx) : 0.0f;
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * (int)blockDim.x + (int)threadIdx.x;
+      const int r = idx / groups, c0 = (idx - r * groups) * N;
+      const int sy = vy_first + r + S.oy, sx0 = c0 + S.ox;
+      rr[u] = r; cc[u] = c0;
+      vec[u] = idx < total && sy >= 0 && sy < S.sh && sx0 >= 0 && sx0 + N <= S.sw && c0 + N <= S.vw;
+      if (vec[u]) Px<T>::load_group(src + (size_t)sy * S.sw + sx0, f[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * (int)blockDim.x + (int)threadIdx.x;
+      if (idx >= total) continue;
+      const int r = rr[u], c0 = cc[u];
+      float *d = L + r * ls + c0;
+      if (vec[u]) {
+#pragma unroll
+        for (int k = 0; k < N; k += 4) *reinterpret_cast<float4 *>(d + k) = make_float4(f[u][k], f[u][k + 1], f[u][k + 2], f[u][k + 3]);
+      } else {
+        const int sy = vy_first + r + S.oy;
+        for (int k = 0; k < N && c0 + k < ls; ++k) {
+          const int sx = min(c0 + k, S.vw - 1) + S.ox;
+          d[k] = (sy >= 0 && sy < S.sh && sx >= 0 && sx < S.sw) ? Px<T>::load(src + (size_t)sy * S.sw + sx) : 0.0f;
+        }
       }
     }
   }
@@ -308,6 +327,146 @@ __global__ __launch_bounds__(256) void revert_resize_kernel(MaskStage S, int row
           Px<T>::store(row + (S.dw - x0 - N), r);
         } else {
           for (int k = 0; k < N && x0 + k < S.dw; ++k) row[S.dw - 1 - (x0 + k)] = v[k];
+        }
+      }
+    }
+  }
+}
+
+// uint8 masks: revert_resize_kernel rebuilt around what the PMC pass and the ISA of that kernel showed.
+//  * With 16 adjacent pixels per lane the horizontal taps of neighbouring lanes lie 16 * (vw / dw) floats apart in the
+//    staged rows -- 5.3 at 640 -> 1920, 8 at 640 -> 1280: every 12th (8th) lane on the same LDS bank, ten bank-conflict
+//    cycles for every LDS issue cycle.  Here a lane owns four runs of 4 adjacent pixels, 4 * lpr pixels apart: for each
+//    of them neighbouring lanes read taps 4 * (vw / dw) floats apart (at most two lanes per bank), and a wave's store
+//    instruction still covers one contiguous run of the row (4 bytes per lane instead of 16).
+//  * The kernel is then bound by its vector ALU (81 % busy), so the row loop is kept to the arithmetic: the vertical
+//    source pair and weight of every row come from a table in LDS (once per strip instead of ten instructions per row
+//    and lane); the two horizontally interpolated source rows live in two register sets whose roles (upper / lower)
+//    alternate as the sweep moves down, instead of being copied from one set to the other; adjacent pixels are paired
+//    for the packed multiply-add; the flip is a template parameter; groups that lie wholly inside the row store without
+//    per-run range checks.
+template <bool FLIP>
+__global__ __launch_bounds__(256) void revert_resize_u8_kernel(MaskStage S, int rows_per_block) {
+  constexpr int N = 16, SUBS = 4;
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) float L[];
+  __shared__ int2 rowtab[64];   // per strip row: {upper | lower << 16 source row, fp32 bits of the lower row's weight}; rows_per_block <= 64
+  const long long mi = blockIdx.y;
+  const int ra = blockIdx.x * rows_per_block, rb = min(ra + rows_per_block, S.dh);
+  if (ra >= rb) return;
+  const uint8_t *src = reinterpret_cast<const uint8_t *>(S.src) + (size_t)mi * S.sh * S.sw;
+  uint8_t *dst = reinterpret_cast<uint8_t *>(S.dst) + (size_t)mi * S.dh * S.dw;
+  const float scale_h = (float)S.vh / (float)S.dh, scale_w = (float)S.vw / (float)S.dw;
+  const int ls = (S.vw + 1 + 3) & ~3;
+  if ((int)threadIdx.x < rb - ra) {
+    int i0, i1; float l0, l1;
+    bilinear_src(scale_h, ra + threadIdx.x, S.vh, i0, i1, l0, l1);
+    rowtab[threadIdx.x] = make_int2(i0 | (i1 << 16), __float_as_int(l1));
+  }
+  const int vy_first = stage_source_rows<uint8_t>(S, src, ra, rb, L, ls);   // ends with the barrier that also covers rowtab
+  const int quads = (S.dw + 3) / 4;                      // runs of 4 pixels in a row
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = (rb - ra + 3) >> 2;                      // every wave sweeps a quarter of the strip's rows, group by group
+  const int y0w = ra + wave * q;
+  typedef float taps __attribute__((ext_vector_type(2), aligned(4)));
+  typedef uint32_t u32_anywhere __attribute__((aligned(1)));
+  // A group: up to SUBS * 64 runs of a row; lane lc owns its runs g0 + j * lpr + lc.  A row's last group may be narrow
+  // (1080 pixels = 256 + 14 runs): its lanes then share out R adjacent rows per instruction instead of idling, so a
+  // group costs what its width is worth.
+  for (int g0 = 0; g0 < quads; g0 += SUBS * 64) {
+    const int lpr = min((min(quads - g0, SUBS * 64) + SUBS - 1) / SUBS, 64);   // lanes per row in this group
+    const int R = 64 / lpr, rsub = lane / lpr;
+    const int lc = lane - rsub * lpr;
+    if (rsub >= R) continue;
+    const int y_first = y0w + rsub, y_last = min(y0w + q, rb), ystep = R;
+    const bool interior = (g0 + SUBS * lpr) * 4 <= S.dw;  // every run of every lane lies wholly inside the row
+    int oa[N];
+    float wa[N], wb[N];
+    int xo[SUBS];                                         // where a run is stored, relative to the row
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int x = (g0 + (k >> 2) * lpr + lc) * 4 + (k & 3);
+      int ia, ib;
+      bilinear_src(scale_w, min(x, S.dw - 1), S.vw, ia, ib, wa[k], wb[k]);
+      oa[k] = ia * 4;
+    }
+#pragma unroll
+    for (int j = 0; j < SUBS; ++j) {
+      const int x = (g0 + j * lpr + lc) * 4;
+      xo[j] = FLIP ? S.dw - x - 4 : x;
+    }
+    // returns the OR of the 16 values' bits: 0 iff the lane's stretch of this source row is all zeros (the taps come
+    // from bytes: no negative zero, no NaN)
+    auto load = [&](f2 (&D)[N / 2], int iy) -> uint32_t {
+      const char *r = reinterpret_cast<const char *>(L + (iy - vy_first) * ls);
+      uint32_t nz = 0;
+#pragma unroll
+      for (int h = 0; h < N / 2; ++h) {
+        const taps a = *reinterpret_cast<const taps *>(r + oa[2 * h]), c = *reinterpret_cast<const taps *>(r + oa[2 * h + 1]);
+        D[h] = f2{fmaf(a.x, wa[2 * h], a.y * wb[2 * h]), fmaf(c.x, wa[2 * h + 1], c.y * wb[2 * h + 1])};
+        nz |= __float_as_uint(D[h].x) | __float_as_uint(D[h].y);
+      }
+      return nz;
+    };
+    auto emit = [&](const f2 (&U)[N / 2], const f2 (&W)[N / 2], uint32_t nz, float ly1, int y) {
+      const float ly0 = 1.0f - ly1;
+      const f2 w0v = {ly0, ly0}, w1v = {ly1, ly1};
+      const int yo = S.flip_ud ? S.dh - 1 - y : y;
+      uint8_t *row = dst + (size_t)yo * S.dw;
+      uint32_t word[SUBS];
+      // masks are mostly background: where both source rows are zero under every lane of the wave, the output is zero
+      // (fma(0, w, 0 * w) = 0) and only the stores remain
+      if (interior && __builtin_amdgcn_ballot_w64(nz != 0) == 0) {
+#pragma unroll
+        for (int j = 0; j < SUBS; ++j) __builtin_nontemporal_store(0u, reinterpret_cast<u32_anywhere *>(row + xo[j]));
+        return;
+      }
+#pragma unroll
+      for (int j = 0; j < SUBS; ++j) {
+        // aten: fma(upper, w_upper, lower * w_lower), two pixels per packed instruction (each half rounds like the scalar
+        // form); `.to(uint8)`: truncation, the values stay inside 0..255
+        const f2 v0 = __builtin_elementwise_fma(U[2 * j], w0v, W[2 * j] * w1v), v1 = __builtin_elementwise_fma(U[2 * j + 1], w0v, W[2 * j + 1] * w1v);
+        const uint32_t b0 = (uint32_t)(int)v0.x, b1 = (uint32_t)(int)v0.y, b2 = (uint32_t)(int)v1.x, b3 = (uint32_t)(int)v1.y;
+        word[j] = FLIP ? (b3 | (b2 << 8)) | ((b1 | (b0 << 8)) << 16) : (b0 | (b1 << 8)) | ((b2 | (b3 << 8)) << 16);
+      }
+      if (interior) {
+#pragma unroll
+        for (int j = 0; j < SUBS; ++j) __builtin_nontemporal_store(word[j], reinterpret_cast<u32_anywhere *>(row + xo[j]));
+      } else {
+#pragma unroll
+        for (int j = 0; j < SUBS; ++j) {
+          const int x = (g0 + j * lpr + lc) * 4;
+          if (x + 4 <= S.dw) {
+            __builtin_nontemporal_store(word[j], reinterpret_cast<u32_anywhere *>(row + xo[j]));
+          } else {
+            for (int k = 0; k < 4 && x + k < S.dw; ++k)   // the row ends inside the run
+              row[FLIP ? S.dw - 1 - (x + k) : x + k] = (uint8_t)(word[j] >> (8 * (FLIP ? 3 - k : k)));
+          }
+        }
+      }
+    };
+    f2 A[N / 2], B[N / 2];
+    uint32_t nzA = 0, nzB = 0;
+    int curA = -1, curB = -1;
+    for (int y = y_first; y < y_last; y += ystep) {
+      const int2 re = rowtab[y - ra];
+      const int iy0 = re.x & 0xffff, iy1 = re.x >> 16;
+      const float ly1 = __int_as_float(re.y);
+      // the upper row is wherever it already is, else it replaces the set that does not hold the lower row
+      const bool upA = curA == iy0 || (curB != iy0 && curB == iy1) || (curB != iy0 && curA != iy1);
+      if (upA) {
+        if (curA != iy0) { nzA = load(A, iy0); curA = iy0; }
+        if (iy1 == iy0) emit(A, A, nzA, ly1, y);
+        else {
+          if (curB != iy1) { nzB = load(B, iy1); curB = iy1; }
+          emit(A, B, nzA | nzB, ly1, y);
+        }
+      } else {
+        if (curB != iy0) { nzB = load(B, iy0); curB = iy0; }
+        if (iy1 == iy0) emit(B, B, nzB, ly1, y);
+        else {
+          if (curA != iy1) { nzA = load(A, iy1); curA = iy1; }
+          emit(B, A, nzA | nzB, ly1, y);
         }
       }
     }
@@ -680,7 +839,11 @@ int lmi_revert_masks_stage(const void *src, int dtype, int64_t m, int src_h, int
     if (lds <= 64 * 1024) {
       dim3 g2((S.dh + rpb - 1) / rpb, (unsigned)m);
       if (dtype == LMI_F32) hipLaunchKernelGGL(revert_resize_kernel<float>, g2, dim3(256), lds, s, S, rpb);
-      else hipLaunchKernelGGL(revert_resize_kernel<uint8_t>, g2, dim3(256), lds, s, S, rpb);
+      // uint8: enlargements of 16x in area and more are bound by their stores, and on rows that are not whole 64-byte
+      // blocks the 16-byte stores of the generic kernel hold up better than 4-byte ones (4K - 4 columns: 301 vs 358 us)
+      else if ((S.dw & 63) != 0 && (long long)S.dh * S.dw >= 16LL * S.vh * S.vw) hipLaunchKernelGGL(revert_resize_kernel<uint8_t>, g2, dim3(256), lds, s, S, rpb);
+      else if (S.flip_lr) hipLaunchKernelGGL(revert_resize_u8_kernel<true>, g2, dim3(256), lds, s, S, rpb);
+      else hipLaunchKernelGGL(revert_resize_u8_kernel<false>, g2, dim3(256), lds, s, S, rpb);
       return lmi_check_launch("revert_resize_kernel");
     }
   }

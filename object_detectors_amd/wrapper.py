@@ -72,6 +72,12 @@ class Yolov8Core:
 
     logger = logging.getLogger(__name__)
     mask_dtype = torch.float32   # the reference returns 0./1. fp32 masks; torch.uint8 writes 4x fewer bytes
+    # `predict` returns time_info = {'preproc', 'proc', 'postproc'} measured with time.time() around each stage, as the
+    # reference does (model.py:281-321).  Neither synchronises the device, so a stage's figure is the time it took to
+    # LAUNCH its work plus whatever the stage itself waits for (postprocess reads the counts back, so it absorbs the
+    # forward pass still running).  Set sync_time_info = True to synchronise at every stage boundary: the figures are
+    # then the stages' real durations, at the cost of the overlap between host and device.
+    sync_time_info = False
 
     def _init(self, weights: str, device='gpu', data=None, fp16=False):
         if not os.path.isfile(weights):
@@ -298,6 +304,11 @@ class Yolov8Core:
         return self._assemble(rows_dev, slot_base, det_h, count_h, keep_h, masks_by_image, orig_imgs, predict_mask, return_segments,
                               _masks_on_device, _with_index)
 
+    def _now(self) -> float:
+        if self.sync_time_info and self.device.type == 'cuda':
+            torch.cuda.synchronize(self.device)
+        return time.time()
+
     def _d2h(self, t: torch.Tensor) -> np.ndarray:
         """`t.cpu().numpy()` through pinned memory (an asynchronous copy at the PCIe rate instead of a pageable one: 116 MB
         of 1080p masks in ~5 instead of ~28 ms).  The array owns its pinned block, which torch's caching host allocator
@@ -370,20 +381,20 @@ class Yolov8Core:
     def predict(self, image, configs, operators=[], iou=0.4, agnostic=False, max_det=300, return_segments=True):
         import gadget_utils.pipeline_utils as pipeline_utils
         time_info = {}
-        t0 = time.time()
+        t0 = self._now()
         im = self.preprocess(image)
-        time_info['preproc'] = time.time() - t0
-        t0 = time.time()
+        time_info['preproc'] = self._now() - t0
+        t0 = self._now()
         pred = self.forward(im)
-        time_info['proc'] = time.time() - t0
-        t0 = time.time()
+        time_info['proc'] = self._now() - t0
+        t0 = self._now()
         # masks of a numpy image stay on the GPU until the operator list is undone there (one launch per stage for
         # all masks instead of the reference's per-mask torch-CPU loop, pipeline_utils.py:408-418)
         on_device = bool(operators) and not isinstance(image, torch.Tensor)
         results = self.postprocess(pred, im, image, configs, iou, agnostic, max_det, return_segments, _masks_on_device=on_device)
         results_dict = collections.defaultdict(list)
         if not len(results['boxes']):
-            time_info['postproc'] = time.time() - t0
+            time_info['postproc'] = self._now() - t0
             return results_dict, time_info
         boxes, scores, classes = results['boxes'][0], results['scores'][0], results['classes'][0]
         if len(results['masks']):
@@ -401,7 +412,7 @@ class Yolov8Core:
         results_dict['boxes'] = pipeline_utils.revert_to_origin(boxes, operators)
         results_dict['scores'] = scores
         results_dict['classes'] = classes
-        time_info['postproc'] = time.time() - t0
+        time_info['postproc'] = self._now() - t0
         return results_dict, time_info
 
     # ---- additive: batched predict on raw frames -------------------------------------------------
@@ -412,18 +423,18 @@ class Yolov8Core:
         in each frame's own pixel space (scale_boxes / process_mask undo the letterbox), so no
         operator list is needed.  Returns (results dict as `postprocess`, time_info)."""
         time_info = {}
-        t0 = time.time()
+        t0 = self._now()
         if isinstance(frames, (np.ndarray, torch.Tensor)) and frames.ndim in (2, 3):   # one frame: (H,W,3), or a grey plane (H,W)
             frames = [frames]
         im, _ = self.letterbox(frames, imgsz, swap_rb=swap_rb)
-        time_info['preproc'] = time.time() - t0
-        t0 = time.time()
+        time_info['preproc'] = self._now() - t0
+        t0 = self._now()
         pred = self.forward(im)
-        time_info['proc'] = time.time() - t0
-        t0 = time.time()
+        time_info['proc'] = self._now() - t0
+        t0 = self._now()
         origs = list(frames) if not isinstance(frames, list) else frames
         results = self.postprocess(pred, im, origs, configs, iou, agnostic, max_det, return_segments, _with_index=_with_index)
-        time_info['postproc'] = time.time() - t0
+        time_info['postproc'] = self._now() - t0
         return results, time_info
 
     @staticmethod
@@ -518,17 +529,17 @@ class Yolov8PoseCore(Yolov8Core):
     def predict(self, image, configs, operators=[], iou=0.4, agnostic=False, max_det=300):
         import gadget_utils.pipeline_utils as pipeline_utils
         time_info = {}
-        t0 = time.time()
+        t0 = self._now()
         im = self.preprocess(image)
-        time_info['preproc'] = time.time() - t0
-        t0 = time.time()
+        time_info['preproc'] = self._now() - t0
+        t0 = self._now()
         pred = self.forward(im)
-        time_info['proc'] = time.time() - t0
-        t0 = time.time()
+        time_info['proc'] = self._now() - t0
+        t0 = self._now()
         results = self.postprocess(pred, im, image, configs, iou, agnostic, max_det)
         results_dict = collections.defaultdict(list)
         if not len(results['boxes']):
-            time_info['postproc'] = time.time() - t0
+            time_info['postproc'] = self._now() - t0
             return results_dict, time_info
         boxes, scores, classes, points = results['boxes'][0], results['scores'][0], results['classes'][0], results['points'][0]
         if len(points) and points.shape[-1] == 3:     # visibility is dropped (model.py:643-645)
@@ -542,7 +553,7 @@ class Yolov8PoseCore(Yolov8Core):
         results_dict['boxes'] = pipeline_utils.revert_to_origin(boxes, operators)
         results_dict['scores'] = scores
         results_dict['classes'] = classes
-        time_info['postproc'] = time.time() - t0
+        time_info['postproc'] = self._now() - t0
         return results_dict, time_info
 
 
@@ -597,17 +608,17 @@ class Yolov8ObbCore(Yolov8Core):
     def predict(self, image, configs, operators=[], iou=0.4, agnostic=False, max_det=300):
         import gadget_utils.pipeline_utils as pipeline_utils
         time_info = {}
-        t0 = time.time()
+        t0 = self._now()
         im = self.preprocess(image)
-        time_info['preproc'] = time.time() - t0
-        t0 = time.time()
+        time_info['preproc'] = self._now() - t0
+        t0 = self._now()
         pred = self.forward(im)
-        time_info['proc'] = time.time() - t0
-        t0 = time.time()
+        time_info['proc'] = self._now() - t0
+        t0 = self._now()
         results = self.postprocess(pred, im, image, configs, iou, agnostic, max_det)
         results_dict = collections.defaultdict(list)
         if not len(results['boxes']):
-            time_info['postproc'] = time.time() - t0
+            time_info['postproc'] = self._now() - t0
             return results_dict, time_info
         boxes, scores, classes = results['boxes'][0], results['scores'][0], results['classes'][0]   # boxes [n_obj, 4, 2]
         n = len(boxes)
@@ -618,5 +629,5 @@ class Yolov8ObbCore(Yolov8Core):
         results_dict['boxes'] = boxes
         results_dict['scores'] = scores
         results_dict['classes'] = classes
-        time_info['postproc'] = time.time() - t0
+        time_info['postproc'] = self._now() - t0
         return results_dict, time_info

@@ -14,7 +14,9 @@ TARGETS = {
     "test_gpu_obb": ["test_rotated_nms_and_finalize", "test_rotated_nms_more_candidates_than_the_lds_sort_buffer"],
     "test_gpu_paste": ["test_paste_masks_vs_torch_grid_sample"],
     "test_gpu_pose": ["test_scale_coords_kernel"],
-    "test_gpu_revert": ["test_revert_points_golden_and_random", "test_revert_masks_letterbox_undo_1080p"],
+    "test_gpu_revert": ["test_revert_points_golden_and_random", "test_revert_masks_letterbox_undo_1080p",
+                        "test_revert_masks_rows_that_are_not_whole_lines"],
+    "test_gpu_nms_pairs": ["test_lists_equal_the_sweep_and_the_oracle_over_batch_sizes", "test_lists_random_settings_ties_caps_and_dtypes"],
 }
 
 def param_sets(fn):

@@ -1,5 +1,5 @@
-"""GPU parity for the suppressor-list form of the axis-aligned NMS (round 3; csrc/nms.hip: nms_pair_lists + the fixpoint
-in nms_sort_suppress): agnostic NMS and models with a handful of classes, in batches that leave every image several CUs.
+"""GPU parity for the suppressor-list form of the axis-aligned NMS (round 3; csrc/nms.hip: nms_pair_lists +
+nms_resolve_lists, nms_sort_suppress for flagged images): agnostic NMS and models with a handful of classes, in batches that leave every image several CUs.
 Replaces the same reference call as the other NMS tests -- `ops.non_max_suppression` at
 object_detectors/yolov8_lmi/model.py:212 (torchvision nms: yolov5_trt.py:267) -- and must give the kept anchors of
 oracle/nms.py, and exactly what the one-workgroup sorted sweep (LMI_NMS_SWEEP_ONLY) gives, row for row."""
@@ -37,7 +37,7 @@ def same(a, b):
 @pytest.mark.parametrize("objects,cluster", [(40, (5, 16)), (110, (8, 16))])
 def test_lists_equal_the_sweep_and_the_oracle_over_batch_sizes(ops, agnostic, nc, objects, cluster):
     """One to 64 images per call: 64 / 16 / 4 workgroups per image share the pair tests; from 65 images on the sweep runs
-    alone (fewer than 4 CUs per image).  The typical and the dense head of the bench, 640 model size."""
+    alone (fewer than 16 CUs per image; 17 to 64 images likewise on this part).  The typical and the dense head of the bench, 640 model size."""
     rng = np.random.default_rng(31 + nc + objects)
     p = synth.head(rng, 6, nc, 0, 640, objects, cluster=cluster)
     ref = ON.non_max_suppression(p, 0.25, 0.45, agnostic=agnostic, nc=nc)
@@ -53,7 +53,7 @@ def test_lists_equal_the_sweep_and_the_oracle_over_batch_sizes(ops, agnostic, nc
 
 
 def test_a_list_longer_than_its_capacity_falls_back_to_the_sweep(ops):
-    """70 nearly identical boxes with descending scores: the last has 69 suppressors, more than a list holds (32) -- the
+    """70 nearly identical boxes with descending scores: the last has 69 suppressors, more than a list holds (48) -- the
     image takes the sorted sweep inside the kernel; its neighbour in the batch, an ordinary scene, keeps its lists."""
     rng = np.random.default_rng(5)
     A = 2100

@@ -101,11 +101,14 @@ def test_revert_masks_letterbox_undo_1080p(ops, dtype):
 @pytest.mark.parametrize("w,h,flip", [
     (1916, 1080, None), (1080, 1920, (True, False)), (500, 375, (False, True)), (333, 250, (True, True)),
     (36, 200, None), (100, 60, (True, False)), (4100, 300, None), (1000, 750, None), (2044, 500, (True, True)),
-    (1917, 1080, (True, False)), (2448, 2048, None), (3836, 600, (False, True)), (516, 1300, None),
+    (1917, 1080, (True, False)), (2448, 2048, None), (3836, 600, (False, True)), (516, 1300, None), (1080, 1920, None),
+    (1280, 720, (True, False)), (2050, 1100, None), (3836, 2160, None),
 ])
 def test_revert_masks_rows_that_are_not_whole_lines(ops, dtype, w, h, flip):
     """Output rows that are not whole 128-byte lines (fp32: revert_resize_lines_kernel, results staged in LDS and
-    written out in chunks cut by absolute address), with the flips folded into the stage, every lane split the host
+    written out in chunks cut by absolute address; uint8: revert_resize_u8_kernel with four runs of 4 pixels per lane,
+    narrow last groups sharing rows between their lanes, the all-background shortcut, or the generic kernel for very
+    large enlargements), with the flips folded into the stage, every lane split the host
     can choose (1-4 chunk columns per lane), widths that are not whole 16-byte chunks, a width beyond the kernel's
     limit and shapes below its threshold (revert_resize_kernel): each mask equals the oracle bit for bit."""
     rng = np.random.default_rng(w * 7 + h)

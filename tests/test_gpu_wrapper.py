@@ -195,6 +195,14 @@ def test_predict_config1_640_det_and_seg(models):
     boxes, scores, classes, _ = oracle_postprocess(pred, None, (640, 640), (640, 640), conf, NAMES, 0.4)
     assert len(boxes) > 0 and np.array_equal(out['boxes'], OG.revert_to_origin(boxes, ops))
     assert np.array_equal(out['scores'], scores) and out['classes'] == classes
+    # time_info: launch times like the reference's by default; real stage durations with sync_time_info (same results)
+    assert set(tinfo) == {'preproc', 'proc', 'postproc'}
+    det.sync_time_info = True
+    try:
+        out2, tsync = det.predict(frame, conf, operators=ops, iou=0.4)
+    finally:
+        det.sync_time_info = False
+    assert np.array_equal(out2['boxes'], out['boxes']) and set(tsync) == set(tinfo) and all(v > 0 for v in tsync.values())
     y = seg.forward(seg.preprocess(frame))
     pred, proto = y[0].cpu().numpy(), y[1][-1][0].cpu().numpy()
     assert pred.shape == (1, 40, 8400) and proto.shape == (32, 160, 160)
