@@ -609,20 +609,14 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(PasteParams P) {
   const float *m = P.masks + (size_t)i * P.hm * P.wm;
   uint8_t *o = P.out + ((size_t)i * P.H + y) * P.W + xq;
 
-  const float gy = (((float)y + 0.5f) - by0) / (by1 - by0) * 2.0f - 1.0f;
-  const float fy = ((gy + 1.0f) * (float)P.hm - 1.0f) / 2.0f;
-  const float fy0 = floorf(fy);
-  const float wy1 = fy - fy0, wy0 = 1.0f - wy1;
-  const int iy0 = (int)fmaxf(fminf(fy0, 1.0e9f), -1.0e9f);
-  const bool r0 = iy0 >= 0 && iy0 < P.hm, r1 = iy0 + 1 >= 0 && iy0 + 1 < P.hm;
-
   // Beyond the box's sampling support (fx in [-1, wm) <=> x + 0.5 within half a mask texel of the box; same for y)
   // every tap lies outside the mask and the sum is exactly 0: those chunks -- most of the frame -- are stored without
   // the per-pixel arithmetic.  The margin (a whole texel + 2 px) is far wider than any rounding; a degenerate or NaN
   // box fails the `> 0` tests and takes the general path.
   const float bw = bx1 - bx0, bh = by1 - by0;
   if (bw > 0.0f && bh > 0.0f) {
-    const float mx = bw / (float)P.wm + 2.0f, my = bh / (float)P.hm + 2.0f;
+    // (v_rcp_f32: the margin need not be exact, and two IEEE divisions per lane were a third of this path)
+    const float mx = bw * __builtin_amdgcn_rcpf((float)P.wm) + 2.0f, my = bh * __builtin_amdgcn_rcpf((float)P.hm) + 2.0f;
     if ((float)(xq + 16) + mx < bx0 || (float)xq - mx > bx1 || (float)(y + 1) + my < by0 || (float)y - my > by1) {
       uint8_t z[16];
 #pragma unroll
@@ -636,6 +630,12 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(PasteParams P) {
     }
   }
 
+  const float gy = (((float)y + 0.5f) - by0) / (by1 - by0) * 2.0f - 1.0f;
+  const float fy = ((gy + 1.0f) * (float)P.hm - 1.0f) / 2.0f;
+  const float fy0 = floorf(fy);
+  const float wy1 = fy - fy0, wy0 = 1.0f - wy1;
+  const int iy0 = (int)fmaxf(fminf(fy0, 1.0e9f), -1.0e9f);
+  const bool r0 = iy0 >= 0 && iy0 < P.hm, r1 = iy0 + 1 >= 0 && iy0 + 1 < P.hm;
   uint8_t v[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
