@@ -17,6 +17,7 @@
 //  revert_resize_lines_kernel  the same for fp32 rows that are not whole 128-byte lines: results through LDS, stores
 //                            cut by absolute address.
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -646,7 +647,9 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(PasteParams P) {
     const float wx1 = fx - fx0, wx0 = 1.0f - wx1;
     const int ix0 = (int)fmaxf(fminf(fx0, 1.0e9f), -1.0e9f);
     const bool c0 = ix0 >= 0 && ix0 < P.wm, c1 = ix0 + 1 >= 0 && ix0 + 1 < P.wm;
-    float acc = 0.0f;
+    // +0, or NaN when a sampling coordinate is not finite (degenerate box): aten multiplies the zero it reads for a tap
+    // outside the mask by that tap's weight, so NaN weights reach the sum and `>= threshold` is false for every threshold
+    float acc = (wy0 * wx0 + wy1 * wx1) * 0.0f;
     if (r0 && c0) acc += m[iy0 * P.wm + ix0] * (wy0 * wx0);
     if (r0 && c1) acc += m[iy0 * P.wm + ix0 + 1] * (wy0 * wx1);
     if (r1 && c0) acc += m[(iy0 + 1) * P.wm + ix0] * (wy1 * wx0);
@@ -702,12 +705,126 @@ __device__ __forceinline__ uint8_t paste_pixel(const PasteParams &P, const Paste
   const float wx1 = fx - fx0, wx0 = 1.0f - wx1;
   const int ix0 = (int)fmaxf(fminf(fx0, 1.0e9f), -1.0e9f);
   const bool c0 = ix0 >= 0 && ix0 < P.wm, c1 = ix0 + 1 >= 0 && ix0 + 1 < P.wm;
-  float acc = 0.0f;
+  float acc = (R.wy0 * wx0 + R.wy1 * wx1) * 0.0f;   // +0, or NaN for a coordinate that is not finite (see paste_masks_kernel)
   if (R.r0 && c0) acc += R.m[R.iy0 * P.wm + ix0] * (R.wy0 * wx0);
   if (R.r0 && c1) acc += R.m[R.iy0 * P.wm + ix0 + 1] * (R.wy0 * wx1);
   if (R.r1 && c0) acc += R.m[(R.iy0 + 1) * P.wm + ix0] * (R.wy1 * wx0);
   if (R.r1 && c1) acc += R.m[(R.iy0 + 1) * P.wm + ix0 + 1] * (R.wy1 * wx1);
   return acc >= P.threshold ? 1 : 0;   // NaN (degenerate box) compares false, like torch
+}
+
+// The paste in two passes (r03; masks up to 60 x 60): paste_masks_kernel spends ~80 instructions on
+// every pixel inside a box's sampling support (two IEEE divisions, four predicated global loads) and ~40 per lane on the
+// chunks outside it, which are most of the frame.
+//  paste_fill_kernel  the constant `0 >= threshold` for the whole output at the memset rate (one workgroup per CU,
+//                     grid-stride, non-temporal 16-byte stores: the pattern of mask_zero_fill_kernel);
+//  paste_box_kernel   only the chunks that meet a box's support: grid (strips of 64 rows, masks), workgroups off the
+//                     support leave at once; the mask sits in LDS inside a border of two zero texels (a tap outside
+//                     the mask then reads a zero instead of being predicated away: `acc += 0 * w` changes nothing);
+//                     every lane owns one 16-pixel chunk column, does its pixels' x arithmetic once and walks down the
+//                     strip's rows, whose y arithmetic comes from a table; per pixel and row what remains is four taps
+//                     (two 8-byte LDS reads), four weight products and the sum, in paste_masks_kernel's order.
+// A box that is degenerate or not finite (NaN compares false throughout) keeps paste_pixel over its whole frame.
+__global__ __launch_bounds__(256) void paste_fill_kernel(uint8_t *out, long long nbytes, uint32_t word) {
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  const u4 v = {word, word, word, word};
+  u4 *o = reinterpret_cast<u4 *>(out);
+  const long long n = nbytes >> 4, stride = (long long)gridDim.x * 256;
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n; g += stride) __builtin_nontemporal_store(v, o + g);
+  if (blockIdx.x == gridDim.x - 1 && (long long)threadIdx.x < (nbytes & 15)) out[(n << 4) + threadIdx.x] = (uint8_t)word;   // rows that are not whole chunks may leave a tail
+}
+
+constexpr int kPasteStrip = 32;    // rows per workgroup
+constexpr int kPasteMaskMax = 60;  // largest mask side the LDS buffer holds (64 x 64 floats with the border)
+
+__global__ __launch_bounds__(256) void paste_box_kernel(PasteParams P) {
+  __shared__ __attribute__((aligned(16))) float M[(kPasteMaskMax + 4) * (kPasteMaskMax + 4)];
+  __shared__ float4 rowtab[kPasteStrip];   // per strip row: {padded upper row index (as int bits), wy0, wy1, -}
+  const int i = blockIdx.y;
+  const float *b = P.boxes + (size_t)i * P.box_stride;
+  const float bx0 = b[0], by0 = b[1], bx1 = b[2], by1 = b[3];
+  const float bw = bx1 - bx0, bh = by1 - by0;
+  const int ra = blockIdx.x * kPasteStrip, rb = min(ra + kPasteStrip, P.H);
+  uint8_t *out = P.out + (size_t)i * P.H * P.W;
+  const bool regular = bw > 0.0f && bh > 0.0f && bw < 1.0e8f && bh < 1.0e8f && fabsf(bx0) < 1.0e8f && fabsf(by0) < 1.0e8f;
+  if (!regular) {   // the general path, pixel by pixel over the strip (uniform over the workgroup)
+    for (int y = ra + (threadIdx.x >> 6); y < rb; y += 4) {
+      PasteRow R;
+      paste_row(P, i, y, R);
+      for (int xq = (threadIdx.x & 63) * 16; xq < P.W; xq += 64 * 16) {
+        uint8_t v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = paste_pixel(P, R, xq + k);
+        if (xq + 16 <= P.W) Px<uint8_t>::store(out + (size_t)y * P.W + xq, v);
+        else for (int k = 0; k < 16 && xq + k < P.W; ++k) out[(size_t)y * P.W + xq + k] = v[k];
+      }
+    }
+    return;
+  }
+  // the support, with paste_masks_kernel's margins: rows and chunk columns outside it hold the constant already
+  const float mx = bw / (float)P.wm + 2.0f, my = bh / (float)P.hm + 2.0f;
+  const int ya = max(ra, (int)floorf(by0 - my) - 1), yb = min(rb, (int)ceilf(by1 + my) + 2);
+  if (ya >= yb) return;
+  const int ca = max(0, ((int)floorf(bx0 - mx) - 1) >> 4), cb = min((P.W + 15) >> 4, (((int)ceilf(bx1 + mx) + 2) + 15) >> 4);
+  if (ca >= cb) return;
+  const int pw = P.wm + 4;
+  const float *m = P.masks + (size_t)i * P.hm * P.wm;
+  for (int t = threadIdx.x; t < (P.hm + 4) * pw; t += 256) {
+    const int r = t / pw - 2, c = t - (r + 2) * pw - 2;
+    M[t] = (r >= 0 && r < P.hm && c >= 0 && c < P.wm) ? m[r * P.wm + c] : 0.0f;
+  }
+  if ((int)threadIdx.x < yb - ya) {
+    const int y = ya + threadIdx.x;
+    const float gy = (((float)y + 0.5f) - by0) / (by1 - by0) * 2.0f - 1.0f;
+    const float fy = ((gy + 1.0f) * (float)P.hm - 1.0f) / 2.0f;
+    const float fy0 = floorf(fy);
+    const float wy1 = fy - fy0, wy0 = 1.0f - wy1;
+    const int iy0 = (int)fmaxf(fminf(fy0, 1.0e9f), -1.0e9f);
+    rowtab[threadIdx.x] = make_float4(__int_as_float(min(max(iy0 + 2, 0), P.hm + 2) * pw * 4), wy0, wy1, 0.0f);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lpr = min(cb - ca, 64);
+  const int R = 64 / lpr, rsub = lane / lpr;
+  const int lc = lane - rsub * lpr;
+  if (rsub >= R) return;
+  const int q = (yb - ya + 3) >> 2;
+  const int y0w = ya + wave * q;
+  typedef float taps __attribute__((ext_vector_type(2), aligned(4)));
+  for (int chunk = ca + lc; chunk < cb; chunk += lpr) {
+    const int xq = chunk * 16;
+    int ox[16];            // byte offset of the left tap's column inside a padded row
+    float wx0[16], wx1[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int x = xq + k;
+      const float gx = (((float)x + 0.5f) - bx0) / (bx1 - bx0) * 2.0f - 1.0f;
+      const float fx = ((gx + 1.0f) * (float)P.wm - 1.0f) / 2.0f;
+      const float fx0 = floorf(fx);
+      wx1[k] = fx - fx0; wx0[k] = 1.0f - wx1[k];
+      const int ix0 = (int)fmaxf(fminf(fx0, 1.0e9f), -1.0e9f);
+      ox[k] = min(max(ix0 + 2, 0), P.wm + 2) * 4;
+    }
+    for (int y = y0w + rsub; y < min(y0w + q, yb); y += R) {
+      const float4 rt = rowtab[y - ya];
+      const char *r0 = reinterpret_cast<const char *>(M) + __float_as_int(rt.x), *r1 = r0 + pw * 4;
+      const float wy0 = rt.y, wy1 = rt.z;
+      uint8_t v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const taps u = *reinterpret_cast<const taps *>(r0 + ox[k]), l = *reinterpret_cast<const taps *>(r1 + ox[k]);
+        float acc = 0.0f;
+        acc += u.x * (wy0 * wx0[k]);
+        acc += u.y * (wy0 * wx1[k]);
+        acc += l.x * (wy1 * wx0[k]);
+        acc += l.y * (wy1 * wx1[k]);
+        v[k] = acc >= P.threshold ? 1 : 0;
+      }
+      // 16-byte stores at whatever address the row gives (rows that are not whole chunks); a chunk the row ends in goes out byte by byte
+      if (xq + 16 <= P.W) Px<uint8_t>::store(out + (size_t)y * P.W + xq, v);
+      else for (int k = 0; k < 16 && xq + k < P.W; ++k) out[(size_t)y * P.W + xq + k] = v[k];
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void paste_masks_flat_kernel(PasteParams P, long long n) {
@@ -852,6 +969,21 @@ int lmi_revert_masks_stage(const void *src, int dtype, int64_t m, int src_h, int
   return lmi_check_launch("revert_masks_kernel");
 }
 
+// CU count of the current device, asked once per device (the paste's fill launches one workgroup per CU)
+static int paste_cu_count() {
+  static std::mutex mu;
+  static int cache[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  std::lock_guard<std::mutex> lock(mu);
+  if (cache[dev] == 0) {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    cache[dev] = ncu;
+  }
+  return cache[dev];
+}
+
 int lmi_paste_masks(const float *masks, int64_t n, int mask_h, int mask_w, const float *boxes, int box_stride, int img_h,
                     int img_w, float threshold, uint8_t *out, void *stream) {
   LMI_REQUIRE(n >= 0 && n <= 65535, LMI_ERR_LIMIT, "lmi_paste_masks: %lld masks not in 0..65535", (long long)n);
@@ -864,6 +996,15 @@ int lmi_paste_masks(const float *masks, int64_t n, int mask_h, int mask_w, const
   P.H = img_h; P.W = img_w; P.threshold = threshold;
   dim3 grid(((img_w + 15) / 16 + 63) / 64, (img_h + 3) / 4, (unsigned)n);
   LMI_REQUIRE(grid.y <= 65535, LMI_ERR_LIMIT, "lmi_paste_masks: image height %d too large", img_h);
+  if (mask_h <= kPasteMaskMax && mask_w <= kPasteMaskMax && lmi_is_aligned(out, 16) && (img_h + kPasteStrip - 1) / kPasteStrip <= 65535) {
+    // the constant everywhere at the memset rate, then the chunks under each box's support
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int cus = paste_cu_count();
+    const uint32_t word = 0.0f >= threshold ? 0x01010101u : 0u;
+    hipLaunchKernelGGL(paste_fill_kernel, dim3((unsigned)cus), dim3(256), 0, s, out, (long long)n * img_h * img_w, word);
+    hipLaunchKernelGGL(paste_box_kernel, dim3((img_h + kPasteStrip - 1) / kPasteStrip, (unsigned)n), dim3(256), 0, s, P);
+    return lmi_check_launch("paste_box_kernel");
+  }
   if ((img_w & 15) != 0 && img_w >= 16 && (long long)img_h * img_w < (1LL << 31) && lmi_is_aligned(out, 16)) {   // rows that are not whole chunks: chunks by absolute address
     const long long chunks = ((long long)n * img_h * img_w + 15) / 16;
     const long long blocks = (chunks + 255) / 256;

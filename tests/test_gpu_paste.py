@@ -72,3 +72,26 @@ def test_paste_masks_edges():
     assert out[0, 6:24, 11:29].all() and out[0].sum() <= 22 * 22 and out[1].sum() == 0
     ref = OP.rescale_masks(m.cpu().numpy(), b.cpu().numpy(), (40, 60), 0.5)
     assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("h,w", [(96, 160), (90, 150)])
+def test_paste_masks_irregular_boxes_thresholds_and_large_masks(h, w):
+    """The two-pass form (constant fill + paste_box_kernel) and what it hands to the per-pixel kernels: boxes that are
+    degenerate, reversed, not finite or astronomically large (paste_box_kernel's general path), a box far outside the
+    image, threshold 0 (the constant outside the boxes is then 1), and masks above 60 x 60 (paste_masks_kernel /
+    paste_masks_flat_kernel): every output equals the oracle's."""
+    from postprocess_utils.mask_utils import rescale_masks
+    rng = np.random.default_rng(h + w)
+    nan, inf = float("nan"), float("inf")
+    b = np.array([[10, 8, 70, 60], [30, 20, 30, 50], [60, 50, 20, 10], [nan, 5, 40, 30], [5, 5, inf, 40], [-3e9, -3e9, 3e9, 3e9],
+                  [-500, -400, -300, -200], [0, 0, w, h], [w - 9.5, h - 7.25, w + 30, h + 40], [12.5, 3.25, 13.0, 80.0]], F32)
+    for s in (28, 64):
+        m = soft_masks(rng, len(b), s)
+        for thr in (0.5, 0.0):
+            got = rescale_masks(torch.from_numpy(m).cuda(), torch.from_numpy(b).cuda(), (h, w), thr).cpu().numpy()
+            with np.errstate(all="ignore"):
+                ref = OP.rescale_masks(m, b, (h, w), thr)
+            assert got.shape == ref.shape
+            for i in range(len(b)):
+                assert (got[i] != ref[i]).mean() < 1e-4, (s, thr, i)   # only pixels whose sampled value sits on the threshold may differ
+            assert np.array_equal(got[1], ref[1]) and np.array_equal(got[3], ref[3]) and np.array_equal(got[6], ref[6])
