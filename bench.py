@@ -88,6 +88,7 @@ class Pipeline:
         self.side = torch.cuda.Stream(device=dev)
         self.decode_done = torch.cuda.Event()
         self.logits = "rows"
+        self.mask_dtype = torch.uint8
 
     def size_masks(self):
         """Survivor count of every batch of the pool (one eager pass each, host sync) -> one mask buffer that holds any."""
@@ -98,7 +99,7 @@ class Pipeline:
             fin = self._nms(i, fork=False)[3]
             cap = max(cap, int(fin["slot_base"][-1].item()))
         self.capacity = cap
-        self.mask_out = torch.empty((cap, self.cfg["h"], self.cfg["w"]), dtype=torch.uint8, device=self.lb_out.device)
+        self.mask_out = torch.empty((cap, self.cfg["h"], self.cfg["w"]), dtype=self.mask_dtype, device=self.lb_out.device)
 
     def _nms(self, i, fork):
         cfg = self.cfg
@@ -157,7 +158,7 @@ class Pipeline:
             join()
         if proto is not None:
             masks, ovf = ops.process_mask(proto, det, fin["slot_map"], fin["slot_base"], (cfg["h"], cfg["w"]),
-                                          self.capacity, torch.uint8, out=self.mask_out, split_events=time_upsample,
+                                          self.capacity, self.mask_dtype, out=self.mask_out, split_events=time_upsample,
                                           # the side stream joins BEFORE the upsample: nothing may run beside the zero fill of
                                           # the masks, whose write pattern collapses under concurrent traffic
                                           # (profiles/r01/write_ceiling.md)
@@ -339,6 +340,9 @@ def main():
     ap.add_argument("--no-block-graph", dest="block_graph", action="store_false",
                     help="replay one HIP graph per step instead of one graph per timed block of --steps steps")
     ap.add_argument("--no-fork", action="store_true", help="run the letterbox and the NMS chain on one stream (measurement)")
+    ap.add_argument("--mask-dtype", default="uint8", choices=["uint8", "float32"],
+                    help="dtype the masks are stored in: uint8 (the headline: SURVEY 8(a) a7 allows it) or float32, the "
+                         "reference's own 0./1. masks and the wrapper's default (four times the bytes)")
     ap.add_argument("--mask-logits", default="rows", choices=["rows", "mfma"],
                     help="coefficient x prototype product: row-sparse vector-ALU kernel (default) or dense fp32 MFMA tiles "
                          "(measurement of the MFMA variant; the LMI_MASK_LOGITS_MFMA flag of lmi_process_mask_ex)")
@@ -386,6 +390,7 @@ def main():
     frames, head, proto = pool[0]
     pipe = Pipeline(cfg, pool)
     pipe.logits = args.mask_logits
+    pipe.mask_dtype = torch.float32 if args.mask_dtype == "float32" else torch.uint8
     pipe.size_masks()
     fork = not args.no_fork
     log(f"[bench r{rank}] inputs ready in {time.perf_counter() - t_gen:.1f}s: {cfg['desc']} (pool of {len(pool)} batches)")
@@ -501,7 +506,7 @@ def main():
         # that meet a box.  The stage is rated as ONE unit: its algorithmic bytes (every output byte once + the
         # logits rows x columns under each box read once) over the HIP-event time around both launches; in the
         # rocprof summary the averages of the listed kernels add up to avg_launch_ms (less the launch gap).
-        kernel = "mask_zero_fill_kernel+mask_box_kernel<uint8>"
+        kernel = "mask_zero_fill_kernel+mask_box_kernel<%s>" % ("uint8" if args.mask_dtype == "uint8" else "float")
         ev_ms = [a.elapsed_time(b) for a, b in evs]
         ms = float(np.mean(ev_ms))
         if os.environ.get("LMI_BENCH_DEBUG_EVENTS"):
@@ -512,7 +517,7 @@ def main():
             torch.cuda.synchronize()
             total = int(fin["slot_base"][-1].item())
             rows = det.view(-1, det.shape[-1])[fin["slot_map"][:total].long()][:, :4].cpu().numpy()
-            algs.append(mask_upsample_bytes_exact(rows, H0, W0, S // 4, S // 4))
+            algs.append(mask_upsample_bytes_exact(rows, H0, W0, S // 4, S // 4, out_elem=pipe.mask_out.element_size()))
         alg = float(np.mean([algs[k % len(pool)] for k in range(n_ev)]))
     else:
         from object_detectors_amd.roofline import letterbox_bytes
@@ -525,7 +530,7 @@ def main():
     # collected separately, gfx950 corrections applied; see profiles/traffic_<workload>.json)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-    if os.path.isfile(tpath):
+    if os.path.isfile(tpath) and args.mask_dtype == "uint8":   # the PMC passes were taken on the headline's uint8 masks
         with open(tpath) as f:
             tk = json.load(f).get("kernels", {})
         parts = [tk.get(k.split("<")[0], {}).get("traffic") for k in kernel.split("+")]
@@ -580,7 +585,7 @@ def main():
                        "input_pool": f"{len(pool)} distinct device-resident batches, rotated every step",
                        "total_images": args.images if args.images > 0 else None,
                        "per_rank": [{"images": int(r["images"]), "survivors": int(r["survivors"]), "kept_checksum": (int(r["chk_hi"]) << 31) | int(r["chk_lo"])} for r in reports],
-                       "mask_dtype": "uint8", "forward": "excluded", "launch": ("one hip graph per block of %d steps" % steps) if block_graph is not None else "one hip graph replay per step" if graphs is not None else "eager",
+                       "mask_dtype": args.mask_dtype, "forward": "excluded", "launch": ("one hip graph per block of %d steps" % steps) if block_graph is not None else "one hip graph replay per step" if graphs is not None else "eager",
                        "streams": "letterbox forked beside NMS sort+suppress+finalize" if fork else "one", "mask_logits": args.mask_logits,
                        "replay_equals_eager": replay_ok,
                        "step_overlap": ("letterbox stream joined once per block: step k+1's candidate filter may run beside step k's letterbox"
