@@ -415,7 +415,9 @@ int lmi_revert_masks_stage(const void *src, int dtype, int64_t m, int src_h, int
  * masks (n, mask_h, mask_w) fp32 are sampled into their boxes (x0,y0,x1,y1 = first four floats of each
  * `box_stride`-float row) over the whole (img_h, img_w) image with aten's bilinear grid_sample
  * (align_corners=False, zero padding) and thresholded with `>=`; out [device] uint8 (n, img_h, img_w) of
- * 0/1 (the reference returns bool).  One launch for all masks, no (n, H, W) fp32 intermediate.
+ * 0/1 (the reference returns bool).  threshold < 0 selects the reference's visualisation mode (:131-133): the
+ * sampled value times 255, truncated like `.to(torch.uint8)`, 0 outside the masks.  No (n, H, W) fp32
+ * intermediate: the constant outside the boxes is written at the memset rate, then the chunks under each box.
  */
 int lmi_paste_masks(const float *masks, int64_t n, int mask_h, int mask_w, const float *boxes,
                     int box_stride, int img_h, int img_w, float threshold, uint8_t *out,

@@ -596,8 +596,16 @@ struct PasteParams {
   const float *boxes;   // (n, box_stride) x0,y0,x1,y1 first
   uint8_t *out;         // (n, H, W) 0/1
   int hm, wm, box_stride, H, W;
-  float threshold;
+  float threshold;   // < 0: the reference's visualisation mode, (value * 255).to(uint8) instead of `>= threshold`
 };
+
+// One output byte from the sampled value: `value >= threshold` -> 0 / 1 (a NaN from a degenerate box compares false,
+// like torch), or for threshold < 0 (mask_utils.py:131-133) the value scaled to 0..255 and truncated like `.to(uint8)`.
+__device__ __forceinline__ uint8_t paste_value(float acc, float threshold) {
+  return threshold >= 0.0f ? (acc >= threshold ? 1 : 0) : (uint8_t)(int)(acc * 255.0f);
+}
+// ... and of a pixel whose taps all lie outside the mask (sampled value exactly 0)
+__device__ __forceinline__ uint8_t paste_outside(float threshold) { return (threshold >= 0.0f && 0.0f >= threshold) ? 1 : 0; }
 
 __global__ __launch_bounds__(256) void paste_masks_kernel(PasteParams P) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -621,7 +629,7 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(PasteParams P) {
     if ((float)(xq + 16) + mx < bx0 || (float)xq - mx > bx1 || (float)(y + 1) + my < by0 || (float)y - my > by1) {
       uint8_t z[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) z[k] = 0.0f >= P.threshold ? 1 : 0;
+      for (int k = 0; k < 16; ++k) z[k] = paste_outside(P.threshold);
       if (xq + 16 <= P.W) {
         Px<uint8_t>::store(o, z);
       } else {
@@ -654,7 +662,7 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(PasteParams P) {
     if (r0 && c1) acc += m[iy0 * P.wm + ix0 + 1] * (wy0 * wx1);
     if (r1 && c0) acc += m[(iy0 + 1) * P.wm + ix0] * (wy1 * wx0);
     if (r1 && c1) acc += m[(iy0 + 1) * P.wm + ix0 + 1] * (wy1 * wx1);
-    v[k] = acc >= P.threshold ? 1 : 0;   // NaN (degenerate box) compares false, like torch
+    v[k] = paste_value(acc, P.threshold);
   }
   if (xq + 16 <= P.W) {
     Px<uint8_t>::store(o, v);
@@ -710,7 +718,7 @@ __device__ __forceinline__ uint8_t paste_pixel(const PasteParams &P, const Paste
   if (R.r0 && c1) acc += R.m[R.iy0 * P.wm + ix0 + 1] * (R.wy0 * wx1);
   if (R.r1 && c0) acc += R.m[(R.iy0 + 1) * P.wm + ix0] * (R.wy1 * wx0);
   if (R.r1 && c1) acc += R.m[(R.iy0 + 1) * P.wm + ix0 + 1] * (R.wy1 * wx1);
-  return acc >= P.threshold ? 1 : 0;   // NaN (degenerate box) compares false, like torch
+  return paste_value(acc, P.threshold);
 }
 
 // The paste in two passes (r03; masks up to 60 x 60): paste_masks_kernel spends ~80 instructions on
@@ -818,7 +826,7 @@ __global__ __launch_bounds__(256) void paste_box_kernel(PasteParams P) {
         acc += u.y * (wy0 * wx1[k]);
         acc += l.x * (wy1 * wx0[k]);
         acc += l.y * (wy1 * wx1[k]);
-        v[k] = acc >= P.threshold ? 1 : 0;
+        v[k] = paste_value(acc, P.threshold);
       }
       // 16-byte stores at whatever address the row gives (rows that are not whole chunks); a chunk the row ends in goes out byte by byte
       if (xq + 16 <= P.W) Px<uint8_t>::store(out + (size_t)y * P.W + xq, v);
@@ -847,7 +855,7 @@ __global__ __launch_bounds__(256) void paste_masks_flat_kernel(PasteParams P, lo
   uint8_t v[16];
   if (paste_row_outside(P, A, x, x + lenA) && (!hasB || paste_row_outside(P, B, 0, 16 - lenA))) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = 0.0f >= P.threshold ? 1 : 0;
+    for (int k = 0; k < 16; ++k) v[k] = paste_outside(P.threshold);
   } else if (lenA == 16) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = paste_pixel(P, A, x + k);
@@ -1000,7 +1008,7 @@ int lmi_paste_masks(const float *masks, int64_t n, int mask_h, int mask_w, const
     // the constant everywhere at the memset rate, then the chunks under each box's support
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int cus = paste_cu_count();
-    const uint32_t word = 0.0f >= threshold ? 0x01010101u : 0u;
+    const uint32_t word = (threshold >= 0.0f && 0.0f >= threshold) ? 0x01010101u : 0u;
     hipLaunchKernelGGL(paste_fill_kernel, dim3((unsigned)cus), dim3(256), 0, s, out, (long long)n * img_h * img_w, word);
     hipLaunchKernelGGL(paste_box_kernel, dim3((img_h + kPasteStrip - 1) / kPasteStrip, (unsigned)n), dim3(256), 0, s, P);
     return lmi_check_launch("paste_box_kernel");

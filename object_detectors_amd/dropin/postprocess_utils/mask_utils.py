@@ -1,5 +1,5 @@
 """Drop-in for the mask-paste helper of lmi_utils/postprocess_utils/mask_utils.py (`rescale_masks`, :66-140):
-same name, arguments and result (bool (N,H,W)); runs in one HIP kernel (object_detectors_amd/csrc/revert.hip).
+same name, arguments and result (bool (N,H,W); uint8 0..255 for threshold < 0); runs in HIP kernels (object_detectors_amd/csrc/revert.hip).
 The convex-hull / polygon helpers of that module (numba, cv2) are outside the accelerated path."""
 import torch
 

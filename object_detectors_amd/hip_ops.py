@@ -654,7 +654,8 @@ def revert_masks(masks: torch.Tensor, operations: Sequence[dict]) -> torch.Tenso
 
 def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, image_shape: Tuple[int, int], threshold: float = 0.5) -> torch.Tensor:
     """`rescale_masks` (lmi_utils/postprocess_utils/mask_utils.py:66-140): (N,Hm,Wm) soft masks pasted into their xyxy
-    boxes of an (H,W) image, `>= threshold`.  Returns a bool tensor (N,H,W) like the reference."""
+    boxes of an (H,W) image, `>= threshold`.  Returns a bool tensor (N,H,W) like the reference; for threshold < 0, like
+    the reference, the sampled values themselves as uint8 (value * 255, truncated)."""
     _need_cuda(masks, "masks")
     _need_cuda(boxes, "boxes")
     if masks.ndim != 3 or masks.shape[-1] != masks.shape[-2]:
@@ -664,12 +665,11 @@ def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, image_shape: Tuple[int
         raise AssertionError(tuple(boxes.shape))
     h, w = int(image_shape[0]), int(image_shape[1])
     out = torch.empty((n, h, w), dtype=torch.uint8, device=masks.device)
+    soft = threshold < 0    # the reference's visualisation mode: (value * 255).to(uint8) instead of a bool mask
     if n == 0:
-        return out.bool()
-    if threshold < 0:
-        raise ValueError("paste_masks: the visualisation mode (threshold < 0, soft uint8 output) is not provided")
+        return out if soft else out.bool()
     m = masks.float().contiguous()
     b = boxes.float().contiguous()
     check(_L.lmi_paste_masks(m.data_ptr(), n, m.shape[1], m.shape[2], b.data_ptr(), b.shape[1], h, w, float(threshold),
                              out.data_ptr(), _stream(m.device)))
-    return out.view(torch.bool)
+    return out if soft else out.view(torch.bool)

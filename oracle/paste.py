@@ -18,7 +18,7 @@ F32 = np.float32
 
 
 def rescale_masks(masks: np.ndarray, boxes: np.ndarray, image_shape, threshold: float = 0.5) -> np.ndarray:
-    """masks (N,Hm,Wm) float in [0,1], boxes (N,4) xyxy -> (N,H,W) bool."""
+    """masks (N,Hm,Wm) float in [0,1], boxes (N,4) xyxy -> (N,H,W) bool (uint8 0..255 for threshold < 0)."""
     img_h, img_w = int(image_shape[0]), int(image_shape[1])
     n = len(masks)
     if n == 0:
@@ -34,6 +34,8 @@ def rescale_masks(masks: np.ndarray, boxes: np.ndarray, image_shape, threshold: 
     gy = img_y[:, :, None].expand(n, img_y.size(1), img_x.size(1))
     grid = torch.stack([gx, gy], dim=3)
     out = F.grid_sample(m, grid, align_corners=False)[:, 0]
+    if threshold < 0:   # the reference's visualisation mode (:131-133)
+        return (out * 255).to(dtype=torch.uint8).numpy()
     return (out >= threshold).numpy()
 
 

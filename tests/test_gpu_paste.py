@@ -95,3 +95,21 @@ def test_paste_masks_irregular_boxes_thresholds_and_large_masks(h, w):
             for i in range(len(b)):
                 assert (got[i] != ref[i]).mean() < 1e-4, (s, thr, i)   # only pixels whose sampled value sits on the threshold may differ
             assert np.array_equal(got[1], ref[1]) and np.array_equal(got[3], ref[3]) and np.array_equal(got[6], ref[6])
+
+
+def test_paste_masks_visualisation_mode():
+    """threshold < 0 (mask_utils.py:131-133): the sampled values times 255 as uint8 instead of a bool mask; equal to the
+    oracle wherever the sampled value times 255 is not within rounding of an integer (the oracle's grid_sample sums its
+    four taps in aten's vectorised order)."""
+    from postprocess_utils.mask_utils import rescale_masks
+    rng = np.random.default_rng(77)
+    for (n, s, h, w) in [(6, 28, 120, 200), (3, 28, 75, 131), (2, 64, 90, 160)]:
+        m = soft_masks(rng, n, s)
+        x0, y0 = rng.uniform(-10, w * 0.5, n), rng.uniform(-10, h * 0.5, n)
+        b = np.stack([x0, y0, x0 + rng.uniform(12, w * 0.5, n), y0 + rng.uniform(12, h * 0.5, n)], 1).astype(F32)
+        got = rescale_masks(torch.from_numpy(m).cuda(), torch.from_numpy(b).cuda(), (h, w), -1.0)
+        assert got.dtype == torch.uint8 and got.shape == (n, h, w)
+        got = got.cpu().numpy().astype(np.int32)
+        ref = OP.rescale_masks(m, b, (h, w), -1.0).astype(np.int32)
+        assert ref.max() > 100 and np.abs(got - ref).max() <= 1 and (got != ref).mean() < 1e-3
+        assert np.array_equal(got == 0, ref == 0) or (np.logical_xor(got == 0, ref == 0)).mean() < 1e-4
