@@ -505,8 +505,14 @@ __global__ __launch_bounds__(256) void mask_zero_fill_kernel(const int *__restri
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
   const u4 zero = {0u, 0u, 0u, 0u};
   u4 *o = reinterpret_cast<u4 *>(out);
-  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n; g += stride) {
-    __builtin_nontemporal_store(zero, o + g);   // plain stores run as fast here but leave write-backs that slow the next kernels
+  // r03: the workgroup's four waves are kept in step by one bare s_barrier per trip (the instruction alone: no wait for
+  // the stores, which a __syncthreads() would add).  Left to themselves the waves drift apart and the window frays:
+  // 6.28-6.37 TB/s without, 6.46-6.54 with the barrier on the same 6.18 GB (scratch/fill_skip.hip,
+  // profiles/r03/fill_skip.md; hipMemset: 6.25-6.40).  The trip count is the same for every lane of the workgroup.
+  for (long long base = (long long)blockIdx.x * 256; base < n; base += stride) {
+    const long long g = base + threadIdx.x;
+    if (g < n) __builtin_nontemporal_store(zero, o + g);   // plain stores run as fast here but leave write-backs that slow the next kernels
+    __builtin_amdgcn_s_barrier();
   }
   if (blockIdx.x == gridDim.x - 1 && (long long)threadIdx.x < (nbytes & 15))
     reinterpret_cast<unsigned char *>(out)[(n << 4) + threadIdx.x] = 0;

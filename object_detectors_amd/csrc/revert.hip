@@ -738,7 +738,11 @@ __global__ __launch_bounds__(256) void paste_fill_kernel(uint8_t *out, long long
   const u4 v = {word, word, word, word};
   u4 *o = reinterpret_cast<u4 *>(out);
   const long long n = nbytes >> 4, stride = (long long)gridDim.x * 256;
-  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n; g += stride) __builtin_nontemporal_store(v, o + g);
+  for (long long base = (long long)blockIdx.x * 256; base < n; base += stride) {   // the waves kept in step as in mask_zero_fill_kernel
+    const long long g = base + threadIdx.x;
+    if (g < n) __builtin_nontemporal_store(v, o + g);
+    __builtin_amdgcn_s_barrier();
+  }
   if (blockIdx.x == gridDim.x - 1 && (long long)threadIdx.x < (nbytes & 15)) out[(n << 4) + threadIdx.x] = (uint8_t)word;   // rows that are not whole chunks may leave a tail
 }
 
