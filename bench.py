@@ -89,6 +89,10 @@ class Pipeline:
         self.decode_done = torch.cuda.Event()
         self.logits = "rows"
         self.mask_dtype = torch.uint8
+        # plan / execute (--lb-plan): the letterbox's coefficient tables depend on the geometry alone, so they can be built
+        # once (hip_ops.letterbox_tables) and every step's letterbox is ONE launch.  Not the default: the timed steps rebuild
+        # them in every call (the table pass hides beside the NMS sort pass: seg640 1.2035 with against 1.2046 ms/step without)
+        self.lb_tables = None
 
     def size_masks(self):
         """Survivor count of every batch of the pool (one eager pass each, host sync) -> one mask buffer that holds any."""
@@ -122,8 +126,8 @@ class Pipeline:
             self._letterbox(i, time_letterbox)
             self._nms(i, fork=False)
         else:
-            self._nms(i, fork=True)
-            self.side.wait_event(self.decode_done)
+            self._nms(i, fork=True)   # (the letterbox enqueued BEFORE the sort pass, so that it starts ~5 us sooner: the sort
+            self.side.wait_event(self.decode_done)   # workgroups then queue behind its tiles -- seg640 1.206 -> 1.234, det640 0.124 -> 0.148 ms/step)
             with torch.cuda.stream(self.side):
                 self._letterbox(i, time_letterbox)
         # join=False (detection workloads inside a block graph): the next step's candidate filter need not wait for this
@@ -144,7 +148,7 @@ class Pipeline:
     def _letterbox(self, i, time_letterbox):
         if time_letterbox is not None:
             time_letterbox[0].record()
-        self.ops.letterbox(self.pool[i][0], (self.S, self.S), pad_value=114, swap_rb=True, out=self.lb_out)
+        self.ops.letterbox(self.pool[i][0], (self.S, self.S), pad_value=114, swap_rb=True, out=self.lb_out, tables=self.lb_tables)
         if time_letterbox is not None:
             time_letterbox[1].record()
 
@@ -235,7 +239,8 @@ def letterbox_targets(device, S=640, B=64):
     (profiles/traffic_det640*.json) over the tap-count bytes."""
     from object_detectors_amd import hip_ops as ops
     from object_detectors_amd.roofline import letterbox_bytes, letterbox_row_granular_bytes
-    out = {"what": f"{B} frames -> ({B},3,{S},{S}) fp32, cold sources (3 rotating batches), HIP events, median of 40"}
+    out = {"what": f"{B} frames -> ({B},3,{S},{S}) fp32, cold sources (3 rotating batches), HIP events, median of 40; "
+                   "*_tables_ready: the geometry's tables built once (hip_ops.letterbox_tables), one launch per call"}
     g = torch.Generator(device=device)
     g.manual_seed(11)
     for tag, h, w, tfile in (("1080p", 1080, 1920, "traffic_det640.json"), ("4k", 2160, 3840, "traffic_det640_4k.json")):
@@ -243,10 +248,13 @@ def letterbox_targets(device, S=640, B=64):
         o = torch.empty((B, 3, S, S), dtype=torch.float32, device=device)
         k = [0]
 
-        def rot():
+        tabs = ops.letterbox_tables((h, w), (S, S), device)
+
+        def rot(tables=tabs):
             k[0] = (k[0] + 1) % 3
-            ops.letterbox(fs[k[0]], (S, S), out=o, pad_value=114, swap_rb=True)
-        us = event_median_us(rot)
+            ops.letterbox(fs[k[0]], (S, S), out=o, pad_value=114, swap_rb=True, tables=tables)
+        us = event_median_us(lambda: rot(None))                             # the ordinary call: table pass + tile kernel
+        out["us_%s_tables_ready" % tag] = round(event_median_us(rot), 1)    # LMI_LB_TABLES_READY: the tile kernel alone
         alg, rowg = B * letterbox_bytes(h, w, S, S, 4), B * letterbox_row_granular_bytes(h, w, S, S, 4)
         out["us_" + tag] = round(us, 1)
         out["frac_spec_" + tag] = round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
@@ -340,6 +348,9 @@ def main():
     ap.add_argument("--no-block-graph", dest="block_graph", action="store_false",
                     help="replay one HIP graph per step instead of one graph per timed block of --steps steps")
     ap.add_argument("--no-fork", action="store_true", help="run the letterbox and the NMS chain on one stream (measurement)")
+    ap.add_argument("--lb-plan", action="store_true",
+                    help="build the letterbox's coefficient tables once per geometry (hip_ops.letterbox_tables) instead of in every call "
+                         "(one launch per letterbox instead of two; measurement -- the default rebuilds them in every timed step)")
     ap.add_argument("--mask-dtype", default="uint8", choices=["uint8", "float32"],
                     help="dtype the masks are stored in: uint8 (the headline: SURVEY 8(a) a7 allows it) or float32, the "
                          "reference's own 0./1. masks and the wrapper's default (four times the bytes)")
@@ -391,6 +402,8 @@ def main():
     pipe = Pipeline(cfg, pool)
     pipe.logits = args.mask_logits
     pipe.mask_dtype = torch.float32 if args.mask_dtype == "float32" else torch.uint8
+    if args.lb_plan:
+        pipe.lb_tables = pipe.ops.letterbox_tables((cfg["h"], cfg["w"]), (cfg["size"], cfg["size"]), device)
     pipe.size_masks()
     fork = not args.no_fork
     log(f"[bench r{rank}] inputs ready in {time.perf_counter() - t_gen:.1f}s: {cfg['desc']} (pool of {len(pool)} batches)")
@@ -587,6 +600,7 @@ def main():
                        "per_rank": [{"images": int(r["images"]), "survivors": int(r["survivors"]), "kept_checksum": (int(r["chk_hi"]) << 31) | int(r["chk_lo"])} for r in reports],
                        "mask_dtype": args.mask_dtype, "forward": "excluded", "launch": ("one hip graph per block of %d steps" % steps) if block_graph is not None else "one hip graph replay per step" if graphs is not None else "eager",
                        "streams": "letterbox forked beside NMS sort+suppress+finalize" if fork else "one", "mask_logits": args.mask_logits,
+                       "letterbox_tables": "built once per geometry (--lb-plan), one launch per step" if args.lb_plan else "rebuilt by every call (two launches)",
                        "replay_equals_eager": replay_ok,
                        "step_overlap": ("letterbox stream joined once per block: step k+1's candidate filter may run beside step k's letterbox"
                                         if (block_graph is not None and args.pipeline_steps and fork and not cfg["nm"]) else "none: every step joins its streams"),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LMI_VERSION 101 /* 0.1.1: lmi_finalize_args grew the keypoint fields */
+#define LMI_VERSION 102 /* 0.1.2: letterbox plan / execute flags (0.1.1: lmi_finalize_args grew the keypoint fields) */
 
 enum lmi_status {
   LMI_OK = 0,
@@ -46,6 +46,13 @@ enum lmi_dtype { LMI_F32 = 0, LMI_F16 = 1, LMI_U8 = 2 };
 enum lmi_resize_mode { LMI_RESIZE_CV2_LINEAR = 0, LMI_RESIZE_TORCH_BILINEAR = 1, LMI_RESIZE_TORCH_BILINEAR_1T = 2 };
 /* OR-ed into `mode`: the source frames are single grey planes (uint8 HW, one byte per pixel) */
 #define LMI_SRC_GRAY 0x100
+/* OR-ed into `mode` (plan / execute, r03): the coefficient tables in `workspace` depend on the sizes alone
+ * (source size, content size, pads, destination size, resampler) -- not on the pixels, the channel order, the pad
+ * value or the output dtype.  LMI_LB_TABLES_ONLY builds them and returns (src / dst may be NULL; the frame
+ * descriptors of lmi_letterbox_u8 are still read); LMI_LB_TABLES_READY says `workspace` still holds the tables of a
+ * call with the same sizes and resampler and leaves the table pass out: one launch per call instead of two. */
+#define LMI_LB_TABLES_ONLY 0x200
+#define LMI_LB_TABLES_READY 0x400
 
 #define LMI_NMS_SWEEP_ONLY 0x100 /* OR-ed into the `rotated` argument of lmi_nms_v8_ex / lmi_nms_suppress_ex */
 

@@ -41,6 +41,7 @@ class lmi_mask_image(C.Structure):
 
 LMI_MASK_LOGITS_MFMA, LMI_MASK_UPSAMPLE_SINGLE, LMI_MASK_PROTO_F16 = 1, 2, 4
 LMI_SRC_GRAY = 0x100
+LMI_LB_TABLES_ONLY, LMI_LB_TABLES_READY = 0x200, 0x400
 LMI_NMS_SWEEP_ONLY = 0x100
 
 

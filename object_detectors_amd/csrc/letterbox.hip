@@ -571,7 +571,7 @@ TabLayout tab_layout(int sets, int dst_h, int dst_w) {
 
 template <typename OutT, bool TORCH, int CH>
 int launch_letterbox_ch(const LbParams &P0, int batch, int sets, int max_pitch128, int max_pitch32, void *workspace,
-                        int64_t workspace_bytes, hipStream_t stream) {
+                        int64_t workspace_bytes, hipStream_t stream, int plan) {
   LbParams P = P0;
   const TabLayout L = tab_layout(sets, P.dst_h, P.dst_w);
   LMI_REQUIRE(workspace != nullptr && lmi_is_aligned(workspace, 256), LMI_ERR_ALIGNMENT, "lmi_letterbox_u8: workspace must be 256-byte aligned");
@@ -581,9 +581,13 @@ int launch_letterbox_ch(const LbParams &P0, int batch, int sets, int max_pitch12
   P.torch = TORCH ? 1 : 0;
   P.xtab = reinterpret_cast<int2 *>(workspace);
   P.ytab = reinterpret_cast<int4 *>(reinterpret_cast<unsigned char *>(workspace) + L.off_y);
-  hipLaunchKernelGGL(letterbox_tables_kernel, dim3((L.xw + P.dst_h + 255) / 256, sets), dim3(256), 0, stream, P);
-  int rc = lmi_check_launch("letterbox_tables_kernel");
-  if (rc) return rc;
+  // plan / execute (r03): the tables depend on the sizes alone -- a caller that letterboxes one geometry again and again
+  // builds them once (LMI_LB_TABLES_ONLY) and leaves the table pass out of every call after that (LMI_LB_TABLES_READY)
+  if (plan != LMI_LB_TABLES_READY) {
+    hipLaunchKernelGGL(letterbox_tables_kernel, dim3((L.xw + P.dst_h + 255) / 256, sets), dim3(256), 0, stream, P);
+    const int rc = lmi_check_launch("letterbox_tables_kernel");
+    if (rc || plan == LMI_LB_TABLES_ONLY) return rc;
+  }
 
   const size_t kMaxLds = 64 * 1024;
   if (lds_bytes_for(max_pitch128) <= kMaxLds) {
@@ -611,27 +615,29 @@ int launch_letterbox_ch(const LbParams &P0, int batch, int sets, int max_pitch12
 
 template <typename OutT, bool TORCH>
 int launch_letterbox(const LbParams &P, int batch, int sets, int ch, int max_pitch128, int max_pitch32, void *workspace,
-                     int64_t workspace_bytes, hipStream_t stream) {
-  return ch == 1 ? launch_letterbox_ch<OutT, TORCH, 1>(P, batch, sets, max_pitch128, max_pitch32, workspace, workspace_bytes, stream)
-                 : launch_letterbox_ch<OutT, TORCH, 3>(P, batch, sets, max_pitch128, max_pitch32, workspace, workspace_bytes, stream);
+                     int64_t workspace_bytes, hipStream_t stream, int plan) {
+  return ch == 1 ? launch_letterbox_ch<OutT, TORCH, 1>(P, batch, sets, max_pitch128, max_pitch32, workspace, workspace_bytes, stream, plan)
+                 : launch_letterbox_ch<OutT, TORCH, 3>(P, batch, sets, max_pitch128, max_pitch32, workspace, workspace_bytes, stream, plan);
 }
 
-int check_common(const void *dst, int dst_h, int dst_w, int dst_dtype, int pad_value, int &mode, int batch, int &ch) {
+int check_common(const void *dst, int dst_h, int dst_w, int dst_dtype, int pad_value, int &mode, int batch, int &ch, int &plan) {
   ch = (mode & LMI_SRC_GRAY) ? 1 : 3;   // the resampler is the low byte of `mode`
-  mode &= ~LMI_SRC_GRAY;
-  LMI_REQUIRE(dst != nullptr, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: dst is NULL");
+  plan = mode & (LMI_LB_TABLES_ONLY | LMI_LB_TABLES_READY);
+  mode &= ~(LMI_SRC_GRAY | LMI_LB_TABLES_ONLY | LMI_LB_TABLES_READY);
+  LMI_REQUIRE(plan != (LMI_LB_TABLES_ONLY | LMI_LB_TABLES_READY), LMI_ERR_BAD_ARG, "lmi_letterbox_u8: LMI_LB_TABLES_ONLY and LMI_LB_TABLES_READY exclude each other");
+  LMI_REQUIRE(dst != nullptr || plan == LMI_LB_TABLES_ONLY, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: dst is NULL");
   LMI_REQUIRE(batch > 0 && batch <= 65535, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: batch %d out of range 1..65535", batch);
   LMI_REQUIRE(dst_h > 0 && dst_w > 0, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: bad destination size %dx%d", dst_h, dst_w);
   LMI_REQUIRE(dst_dtype == LMI_F32 || dst_dtype == LMI_F16, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: dst_dtype must be LMI_F32 or LMI_F16");
   LMI_REQUIRE(pad_value >= 0 && pad_value <= 255, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: pad_value %d not in 0..255", pad_value);
   LMI_REQUIRE(mode == LMI_RESIZE_CV2_LINEAR || mode == LMI_RESIZE_TORCH_BILINEAR || mode == LMI_RESIZE_TORCH_BILINEAR_1T, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: unknown resize mode %d", mode);
-  LMI_REQUIRE(lmi_is_aligned(dst, 16), LMI_ERR_ALIGNMENT, "lmi_letterbox_u8: dst must be 16-byte aligned");
+  LMI_REQUIRE(lmi_is_aligned(dst, 16), LMI_ERR_ALIGNMENT, "lmi_letterbox_u8: dst must be 16-byte aligned");   // (NULL passes)
   return LMI_OK;
 }
 
 int check_frame(const void *src, int h, int w, long long stride, int new_w, int new_h, int pad_l, int pad_t, int dst_h, int dst_w, int i,
-                int ch, bool may_crop = false) {
-  LMI_REQUIRE(src != nullptr, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frame %d: src is NULL", i);
+                int ch, bool may_crop = false, bool tables_only = false) {
+  LMI_REQUIRE(src != nullptr || tables_only, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frame %d: src is NULL", i);
   LMI_REQUIRE(h > 0 && w > 0 && stride >= (long long)ch * w, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frame %d: bad size/stride (%d,%d,%lld)", i, h, w, stride);
   LMI_REQUIRE((long long)(h - 1) * stride + (long long)ch * w < (1LL << 32) - 32, LMI_ERR_LIMIT, "lmi_letterbox_u8: frame %d larger than 4 GiB", i);
   // the torch flavour may place the content partly outside the destination (fit_im_to_size crops, centred)
@@ -652,15 +658,15 @@ int64_t lmi_letterbox_workspace_bytes(int table_sets, int dst_h, int dst_w) {
 int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, int batch, void *dst, int dst_h,
                      int dst_w, int dst_dtype, int pad_value, int swap_rb, int mode, void *workspace,
                      int64_t workspace_bytes, void *stream) {
-  int ch = 3;
-  int rc = check_common(dst, dst_h, dst_w, dst_dtype, pad_value, mode, batch, ch);
+  int ch = 3, plan = 0;
+  int rc = check_common(dst, dst_h, dst_w, dst_dtype, pad_value, mode, batch, ch, plan);
   if (rc) return rc;
   LMI_REQUIRE(frames_host != nullptr && frames_dev != nullptr, LMI_ERR_BAD_ARG, "lmi_letterbox_u8: frames is NULL");
   int p128 = 0, p32 = 0;
   for (int i = 0; i < batch; ++i) {
     const lmi_frame &f = frames_host[i];
     rc = check_frame(reinterpret_cast<const void *>(f.src), f.h, f.w, f.row_stride, f.new_w, f.new_h, f.pad_l, f.pad_t, dst_h, dst_w, i,
-                     ch, mode != LMI_RESIZE_CV2_LINEAR);
+                     ch, mode != LMI_RESIZE_CV2_LINEAR, plan == LMI_LB_TABLES_ONLY);
     if (rc) return rc;
     int a = lds_pitch_for(f.w, f.new_w, 128, ch), b = lds_pitch_for(f.w, f.new_w, 32, ch);
     if (a > p128) p128 = a;
@@ -674,20 +680,22 @@ int lmi_letterbox_u8(const lmi_frame *frames_host, const lmi_frame *frames_dev, 
   if (mode != LMI_RESIZE_CV2_LINEAR) {
     // with a workspace for the tables: the LDS-staged kernel (249 -> ~100 us per 64 x 1080p); without one, the
     // table-free kernel that reads its taps straight from global memory (the entry's contract before r02)
-    if (workspace == nullptr || workspace_bytes < lmi_letterbox_workspace_bytes(batch, dst_h, dst_w))
+    if (workspace == nullptr || workspace_bytes < lmi_letterbox_workspace_bytes(batch, dst_h, dst_w)) {
+      LMI_REQUIRE(plan == 0, LMI_ERR_WORKSPACE, "lmi_letterbox_u8: LMI_LB_TABLES_ONLY / _READY need a workspace for the tables");
       return dst_dtype == LMI_F32 ? launch_letterbox_torch<float>(P, batch, ch, s) : launch_letterbox_torch<__half>(P, batch, ch, s);
-    return dst_dtype == LMI_F32 ? launch_letterbox<float, true>(P, batch, batch, ch, p128, p32, workspace, workspace_bytes, s)
-                                : launch_letterbox<__half, true>(P, batch, batch, ch, p128, p32, workspace, workspace_bytes, s);
+    }
+    return dst_dtype == LMI_F32 ? launch_letterbox<float, true>(P, batch, batch, ch, p128, p32, workspace, workspace_bytes, s, plan)
+                                : launch_letterbox<__half, true>(P, batch, batch, ch, p128, p32, workspace, workspace_bytes, s, plan);
   }
-  return dst_dtype == LMI_F32 ? launch_letterbox<float, false>(P, batch, batch, ch, p128, p32, workspace, workspace_bytes, s)
-                              : launch_letterbox<__half, false>(P, batch, batch, ch, p128, p32, workspace, workspace_bytes, s);
+  return dst_dtype == LMI_F32 ? launch_letterbox<float, false>(P, batch, batch, ch, p128, p32, workspace, workspace_bytes, s, plan)
+                              : launch_letterbox<__half, false>(P, batch, batch, ch, p128, p32, workspace, workspace_bytes, s, plan);
 }
 
 int lmi_letterbox_u8_uniform(const void *src, int batch, int h, int w, int64_t row_stride, int64_t image_stride,
                              void *dst, int dst_h, int dst_w, int dst_dtype, int pad_value, int swap_rb, int stretch,
                              int mode, void *workspace, int64_t workspace_bytes, void *stream) {
-  int ch = 3;
-  int rc = check_common(dst, dst_h, dst_w, dst_dtype, pad_value, mode, batch, ch);
+  int ch = 3, plan = 0;
+  int rc = check_common(dst, dst_h, dst_w, dst_dtype, pad_value, mode, batch, ch, plan);
   if (rc) return rc;
   // this form derives the geometry itself, by the cv2 / ultralytics rules (round(), centred pad); the reference
   // helpers behind the torch flavours size and pad differently (int() truncation, pipeline_utils.py:36-39,110-131),
@@ -697,7 +705,7 @@ int lmi_letterbox_u8_uniform(const void *src, int batch, int h, int w, int64_t r
   int32_t g[6];
   rc = lmi_letterbox_geometry(h, w, dst_h, dst_w, stretch, g);
   if (rc) return rc;
-  rc = check_frame(src, h, w, row_stride, g[0], g[1], g[2], g[4], dst_h, dst_w, 0, ch);
+  rc = check_frame(src, h, w, row_stride, g[0], g[1], g[2], g[4], dst_h, dst_w, 0, ch, false, plan == LMI_LB_TABLES_ONLY);
   if (rc) return rc;
   LMI_REQUIRE(batch == 1 || image_stride >= (int64_t)(h - 1) * row_stride + (int64_t)ch * w, LMI_ERR_BAD_ARG,
               "lmi_letterbox_u8_uniform: image_stride %lld must cover a frame", (long long)image_stride);
@@ -709,8 +717,8 @@ int lmi_letterbox_u8_uniform(const void *src, int batch, int h, int w, int64_t r
   P.dst = dst; P.dst_h = dst_h; P.dst_w = dst_w; P.pad_value = pad_value; P.swap_rb = swap_rb ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int p128 = lds_pitch_for(w, g[0], 128, ch), p32 = lds_pitch_for(w, g[0], 32, ch);
-  return dst_dtype == LMI_F32 ? launch_letterbox<float, false>(P, batch, 1, ch, p128, p32, workspace, workspace_bytes, s)
-                              : launch_letterbox<__half, false>(P, batch, 1, ch, p128, p32, workspace, workspace_bytes, s);
+  return dst_dtype == LMI_F32 ? launch_letterbox<float, false>(P, batch, 1, ch, p128, p32, workspace, workspace_bytes, s, plan)
+                              : launch_letterbox<__half, false>(P, batch, 1, ch, p128, p32, workspace, workspace_bytes, s, plan);
 }
 
 int lmi_preprocess_u8(const void *src, int h, int w, int c, int64_t row_stride, void *dst, int dst_dtype, void *stream) {

@@ -158,9 +158,26 @@ def _check_lb_out(out, b, dst_h, dst_w, tdt, dev) -> None:
         raise ValueError(f"letterbox: `out` must be a contiguous {tdt} tensor of shape {(b, 3, dst_h, dst_w)} on the frames' device")
 
 
+def letterbox_tables(frame_hw: Tuple[int, int], dst_hw: Tuple[int, int], device, stretch: bool = False) -> torch.Tensor:
+    """Plan half of the uniform cv2-flavoured letterbox (LMI_LB_TABLES_ONLY): the coefficient tables of one geometry
+    -- every frame (h, w), destination dst_hw -- built once on the current stream into a buffer the CALLER owns.  Hand it
+    to `letterbox(..., tables=t)` and every such call is one launch instead of two; the tables depend on the sizes
+    alone (not on pixels, channel order, pad value or dtype), so one buffer serves every call of that geometry, from any
+    stream that is ordered after this call, and inside HIP graphs (the buffer must outlive them)."""
+    h, w = int(frame_hw[0]), int(frame_hw[1])
+    dst_h, dst_w = int(dst_hw[0]), int(dst_hw[1])
+    device = torch.device(device)
+    t = torch.empty((int(_L.lmi_letterbox_workspace_bytes(1, dst_h, dst_w)),), dtype=torch.uint8, device=device)
+    check(_L.lmi_letterbox_u8_uniform(None, 1, h, w, 3 * w, 3 * w * h, None, dst_h, dst_w, LMI_F32, 0, 0, int(stretch),
+                                      _lib.LMI_LB_TABLES_ONLY, t.data_ptr(), t.numel(), _stream(device)))
+    t._lmi_tables_key = (h, w, dst_h, dst_w, bool(stretch), device.index)
+    return t
+
+
 def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple[int, int], pad_value: int = 114,
               swap_rb: bool = False, fp16: bool = False, stretch: bool = False,
-              out: Optional[torch.Tensor] = None, mode: str = "cv2", resize=None, torch_threads: Optional[int] = None):
+              out: Optional[torch.Tensor] = None, mode: str = "cv2", resize=None, torch_threads: Optional[int] = None,
+              tables: Optional[torch.Tensor] = None):
     """Fused resize + centred pad + channel swap + /255 + NCHW.
 
     frames: a (B,H,W,3) uint8 tensor (uniform batch) or a sequence of (H,W,3) uint8 tensors of any
@@ -172,6 +189,8 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
     `--resize`, either side None; pads may be negative = centred crop; pad value 0 is the helpers' default).
     torch_threads=1 reproduces what those helpers give when torch runs on exactly one thread (aten then picks
     its other CPU kernel for 3-channel frames); any other value: the >= 2-thread result.
+    tables: what `letterbox_tables` returned for this geometry (uniform (B,H,W,C) batches, mode 'cv2'): the table pass
+    is left out of the call (LMI_LB_TABLES_READY).
     """
     dst_h, dst_w = int(dst_hw[0]), int(dst_hw[1])
     tdt, ldt = _dt(fp16)
@@ -198,13 +217,21 @@ def letterbox(frames: Union[torch.Tensor, Sequence[torch.Tensor]], dst_hw: Tuple
             out = torch.empty((b, 3, dst_h, dst_w), dtype=tdt, device=frames.device)
         else:
             _check_lb_out(out, b, dst_h, dst_w, tdt, frames.device)
-        ws = _ws.get(frames.device, "letterbox", int(_L.lmi_letterbox_workspace_bytes(1, dst_h, dst_w)))
+        flags = _lib.LMI_SRC_GRAY if ch == 1 else 0
+        if tables is not None:
+            if getattr(tables, "_lmi_tables_key", None) != (h, w, dst_h, dst_w, bool(stretch), frames.device.index):
+                raise ValueError("letterbox: `tables` were not built by letterbox_tables for this geometry and device")
+            ws, flags = tables, flags | _lib.LMI_LB_TABLES_READY
+        else:
+            ws = _ws.get(frames.device, "letterbox", int(_L.lmi_letterbox_workspace_bytes(1, dst_h, dst_w)))
         check(_L.lmi_letterbox_u8_uniform(frames.data_ptr(), b, h, w, frames.stride(1), frames.stride(0), out.data_ptr(),
-                                          dst_h, dst_w, ldt, pad_value, int(swap_rb), int(stretch), _lib.LMI_SRC_GRAY if ch == 1 else 0, ws.data_ptr(),
+                                          dst_h, dst_w, ldt, pad_value, int(swap_rb), int(stretch), flags, ws.data_ptr(),
                                           ws.numel(), _stream(frames.device)))
         g = letterbox_geometry(h, w, dst_h, dst_w, stretch)
         ops = [[{"resize": [g[0], g[1], w, h]}, {"pad": [g[2], g[3], g[4], g[5]]}] for _ in range(b)]
         return out, ops
+    if tables is not None:
+        raise ValueError("letterbox: tables= serves uniform (B,H,W,C) batches in mode 'cv2'")
     frames = list(frames)
     if not frames:
         raise ValueError("letterbox: empty batch")

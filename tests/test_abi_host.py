@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_typed(lib):
 
 
 def test_version_and_status_strings(lib):
-    assert lib.lmi_version() == 101
+    assert lib.lmi_version() == 102
     assert lib.lmi_status_string(0) == b"ok"
     assert b"workspace" in lib.lmi_status_string(-3)
 

@@ -74,6 +74,34 @@ def test_letterbox_bit_exact_uniform(ops, h, w, sh, sw):
         assert bad.shape[0] == 0, f"{bad.shape[0]} mismatching elements, first (c,y,x): {bad[:8].tolist()}"
 
 
+def test_letterbox_plan_execute_tables_built_once(ops):
+    """LMI_LB_TABLES_ONLY / LMI_LB_TABLES_READY: the tables of a geometry are built once into a caller-owned buffer; calls
+    that leave the table pass out equal the oracle (and the ordinary call) whatever the pixels, channel order, pad value,
+    dtype or grey / colour -- and a buffer built for another geometry is refused."""
+    rng = np.random.default_rng(77)
+    for h, w, sh, sw, stretch in [(375, 500, 640, 640, False), (1080, 1920, 640, 640, False), (33, 77, 96, 128, True)]:
+        tabs = ops.letterbox_tables((h, w), (sh, sw), "cuda:0", stretch=stretch)
+        for swap, pad, fp16, grey in [(True, 114, False, False), (False, 0, True, False), (True, 7, False, True)]:
+            frames = synth.frames_u8(rng, 3, h, w)
+            f = frames[..., :1] if grey else frames
+            got, gops = ops.letterbox(dev(f), (sh, sw), pad_value=pad, swap_rb=swap, fp16=fp16, stretch=stretch, tables=tabs)
+            plain, pops = ops.letterbox(dev(f), (sh, sw), pad_value=pad, swap_rb=swap, fp16=fp16, stretch=stretch)
+            assert gops == pops and torch.equal(got, plain)
+            got = got.cpu().numpy()
+            for b in range(3):
+                src = np.repeat(f[b], 3, axis=2) if grey else f[b]
+                ref, rops = OC.letterbox_u8(src, sh, sw, pad_value=pad, swap_rb=swap, fp16=fp16, stretch=stretch)
+                assert gops[b] == rops and np.array_equal(bits(got[b]), bits(ref))
+        with pytest.raises(ValueError):
+            ops.letterbox(dev(synth.frames_u8(rng, 1, h + 1, w)), (sh, sw), stretch=stretch, tables=tabs)
+    with pytest.raises(ValueError):   # both flags at once
+        from object_detectors_amd import _lib
+        t = ops.letterbox_tables((64, 64), (32, 32), "cuda:0")
+        o = torch.empty((1, 3, 32, 32), device="cuda")
+        _lib.check(_lib.load().lmi_letterbox_u8_uniform(dev(synth.frames_u8(rng, 1, 64, 64)).data_ptr(), 1, 64, 64, 192, 64 * 192, o.data_ptr(), 32, 32, 0,
+                                                        0, 0, 0, _lib.LMI_LB_TABLES_ONLY | _lib.LMI_LB_TABLES_READY, t.data_ptr(), t.numel(), 0))
+
+
 def test_letterbox_ragged_batch_fp16_stretch_and_rgb(ops):
     rng = np.random.default_rng(5)
     sizes = [(375, 500), (1080, 1920), (427, 640), (64, 48), (640, 640), (33, 1000)]
