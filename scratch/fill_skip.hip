@@ -60,6 +60,26 @@ __global__ __launch_bounds__(256) void fill_bar_2k(u4 *out, size_t nvec) {
   }
 }
 
+// barrier-paced fill with at most K + 1 stores of a wave in flight (s_waitcnt vmcnt(K) after every store)
+template <int K, bool BAR>
+__global__ __launch_bounds__(256) void fill_throttle(u4 *out, size_t nvec) {
+  const u4 z = {0u, 0u, 0u, 0u};
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t base = (size_t)blockIdx.x * 256; base < nvec; base += stride) {
+    if (base + threadIdx.x < nvec) __builtin_nontemporal_store(z, out + base + threadIdx.x);
+    if (K == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (K == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    if (K == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if (K == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (K == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (K == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if (K == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (K == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    if (K == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if (BAR) __builtin_amdgcn_s_barrier();
+  }
+}
+
 typedef uint32_t u16v __attribute__((ext_vector_type(16)));
 // Every entry is a whole 4 KiB block (its first 128-byte line): a run's last block ends at the run's end (it may overlap
 // the block before), a run shorter than a block spills into the box rows behind it, which the row pass rewrites.  The
@@ -255,6 +275,32 @@ int main() {
     const float d = run([&] { hipLaunchKernelGGL(fill_bar_2k, dim3(128), dim3(256), 0, 0, buf, nvec); }, 20);
     printf("barrier-paced %d: identity map %.4f ms (%.0f) | XCD-contiguous map %.4f (%.0f) | 2 KiB per wave and trip, grid 256 %.4f (%.0f) | grid 128 %.4f (%.0f)\n", rep,
            a, bytes / a / 1e6, b, bytes / b / 1e6, c, bytes / c / 1e6, d, bytes / d / 1e6);
+  }
+  for (int rep = 0; rep < 2; ++rep) {
+    const float r0 = run([&] { hipLaunchKernelGGL((fill_plain_bar<1, 256>), dim3(256), dim3(256), 0, 0, buf, nvec); }, 20);
+    const float a = run([&] { hipLaunchKernelGGL((fill_throttle<1, true>), dim3(256), dim3(256), 0, 0, buf, nvec); }, 20);
+    const float b = run([&] { hipLaunchKernelGGL((fill_throttle<2, true>), dim3(256), dim3(256), 0, 0, buf, nvec); }, 20);
+    const float c = run([&] { hipLaunchKernelGGL((fill_throttle<4, true>), dim3(256), dim3(256), 0, 0, buf, nvec); }, 20);
+    const float d = run([&] { hipLaunchKernelGGL((fill_throttle<8, true>), dim3(256), dim3(256), 0, 0, buf, nvec); }, 20);
+    const float e = run([&] { hipLaunchKernelGGL((fill_throttle<16, true>), dim3(256), dim3(256), 0, 0, buf, nvec); }, 20);
+    const float f = run([&] { hipLaunchKernelGGL((fill_throttle<2, false>), dim3(256), dim3(256), 0, 0, buf, nvec); }, 20);
+    const float g = run([&] { hipLaunchKernelGGL((fill_throttle<4, false>), dim3(256), dim3(256), 0, 0, buf, nvec); }, 20);
+    const float h = run([&] { hipLaunchKernelGGL((fill_throttle<8, false>), dim3(256), dim3(256), 0, 0, buf, nvec); }, 20);
+    printf("stores in flight %d: barrier only %.4f ms (%.0f) | barrier + vmcnt 1/2/4/8/16: %.4f (%.0f) %.4f (%.0f) %.4f (%.0f) %.4f (%.0f) %.4f (%.0f) | vmcnt 2/4/8 alone: %.4f (%.0f) %.4f (%.0f) %.4f (%.0f)\n", rep,
+           r0, bytes / r0 / 1e6, a, bytes / a / 1e6, b, bytes / b / 1e6, c, bytes / c / 1e6, d, bytes / d / 1e6, e, bytes / e / 1e6, f, bytes / f / 1e6, g, bytes / g / 1e6, h, bytes / h / 1e6);
+  }
+  for (int rep = 0; rep < 6; ++rep) {
+    const float r0 = run([&] { hipLaunchKernelGGL((fill_plain_bar<1, 256>), dim3(256), dim3(256), 0, 0, buf, nvec); }, 20);
+    const float a = run([&] { hipLaunchKernelGGL((fill_throttle<6, true>), dim3(256), dim3(256), 0, 0, buf, nvec); }, 20);
+    const float b = run([&] { hipLaunchKernelGGL((fill_throttle<8, true>), dim3(256), dim3(256), 0, 0, buf, nvec); }, 20);
+    const float c = run([&] { hipLaunchKernelGGL((fill_throttle<10, true>), dim3(256), dim3(256), 0, 0, buf, nvec); }, 20);
+    const float d = run([&] { hipLaunchKernelGGL((fill_throttle<12, true>), dim3(256), dim3(256), 0, 0, buf, nvec); }, 20);
+    printf("A/B throttle %d: barrier only %.4f (%.0f) | + vmcnt 6 %.4f (%.0f) | 8 %.4f (%.0f) | 10 %.4f (%.0f) | 12 %.4f (%.0f)\n", rep, r0, bytes / r0 / 1e6,
+           a, bytes / a / 1e6, b, bytes / b / 1e6, c, bytes / c / 1e6, d, bytes / d / 1e6);
+  }
+  for (int gsz : {224, 240, 248, 256}) {
+    const float a = run([&] { hipLaunchKernelGGL((fill_plain_bar<1, 256>), dim3(gsz), dim3(256), 0, 0, buf, nvec); }, 20);
+    printf("barrier-paced, grid %d: %.4f ms (%.0f)\n", gsz, a, bytes / a / 1e6);
   }
   const float tr = run([&] { hipLaunchKernelGGL(fill_rows, dim3((H + 15) / 16, S), dim3(256), 0, 0, drows, H, W16, buf); });
   printf("rows under the boxes, zeros only: %.3f ms (%.0f GB/s of %.2f GB)\n", tr, skipped / tr / 1e6, skipped / 1e9);
