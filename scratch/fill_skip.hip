@@ -80,38 +80,6 @@ __global__ __launch_bounds__(256) void fill_throttle(u4 *out, size_t nvec) {
   }
 }
 
-// barrier-paced fill whose workgroups also wait for each other, one phase behind: after every K trips a workgroup adds
-// one to the phase's counter (no return value: nothing waits for it) and, before it goes on, looks at the counter of the
-// phase BEFORE the one it has just finished -- a scalar load past the scalar cache, so the stores are not drained -- and
-// sleeps while some workgroup has not reached it.  Bounded: after `limit` looks it stops looking for good.
-template <int K>
-__global__ __launch_bounds__(256) void fill_sync(u4 *out, size_t nvec, unsigned *cnt, unsigned target, int limit) {
-  const u4 z = {0u, 0u, 0u, 0u};
-  const size_t stride = (size_t)gridDim.x * 256;
-  int k = 0, phase = 0;
-  bool sync = true;
-  for (size_t base = (size_t)blockIdx.x * 256; base < nvec; base += stride) {
-    if (base + threadIdx.x < nvec) __builtin_nontemporal_store(z, out + base + threadIdx.x);
-    if (++k == K) {
-      k = 0;
-      if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt + phase, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (phase >= 1 && sync && threadIdx.x < 64) {   // wave 0 looks, the others wait for it at the barrier below
-        const unsigned *p = cnt + phase - 1;
-        int looks = 0;
-        for (;;) {
-          unsigned v;
-          asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
-          if (v >= target) break;
-          if (++looks >= limit) { sync = false; break; }
-          __builtin_amdgcn_s_sleep(4);
-        }
-      }
-      ++phase;
-    }
-    __builtin_amdgcn_s_barrier();
-  }
-}
-
 typedef uint32_t u16v __attribute__((ext_vector_type(16)));
 // Every entry is a whole 4 KiB block (its first 128-byte line): a run's last block ends at the run's end (it may overlap
 // the block before), a run shorter than a block spills into the box rows behind it, which the row pass rewrites.  The
@@ -329,23 +297,6 @@ int main() {
     const float d = run([&] { hipLaunchKernelGGL((fill_throttle<12, true>), dim3(256), dim3(256), 0, 0, buf, nvec); }, 20);
     printf("A/B throttle %d: barrier only %.4f (%.0f) | + vmcnt 6 %.4f (%.0f) | 8 %.4f (%.0f) | 10 %.4f (%.0f) | 12 %.4f (%.0f)\n", rep, r0, bytes / r0 / 1e6,
            a, bytes / a / 1e6, b, bytes / b / 1e6, c, bytes / c / 1e6, d, bytes / d / 1e6);
-  }
-  {
-    unsigned *cnt; CK(hipMalloc(&cnt, 4096 * 4)); CK(hipMemset(cnt, 0, 4096 * 4));
-    unsigned epoch = 0;
-    auto sync_run = [&](auto kern) {
-      return run([&] { ++epoch; hipLaunchKernelGGL(kern, dim3(256), dim3(256), 0, 0, buf, nvec, cnt, epoch * 256u, 64); }, 20);
-    };
-    for (int rep = 0; rep < 4; ++rep) {
-      const float r0 = run([&] { hipLaunchKernelGGL((fill_plain_bar<1, 256>), dim3(256), dim3(256), 0, 0, buf, nvec); }, 20);
-      const float a = sync_run(fill_sync<8>);
-      const float b = sync_run(fill_sync<16>);
-      const float c = sync_run(fill_sync<32>);
-      const float d = sync_run(fill_sync<64>);
-      printf("cross-workgroup sync %d: barrier only %.4f (%.0f) | every 8 trips %.4f (%.0f) | 16 %.4f (%.0f) | 32 %.4f (%.0f) | 64 %.4f (%.0f)\n", rep, r0, bytes / r0 / 1e6,
-             a, bytes / a / 1e6, b, bytes / b / 1e6, c, bytes / c / 1e6, d, bytes / d / 1e6);
-    }
-    CK(hipFree(cnt));
   }
   for (int gsz : {224, 240, 248, 256}) {
     const float a = run([&] { hipLaunchKernelGGL((fill_plain_bar<1, 256>), dim3(gsz), dim3(256), 0, 0, buf, nvec); }, 20);
