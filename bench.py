@@ -126,8 +126,11 @@ class Pipeline:
             self._letterbox(i, time_letterbox)
             self._nms(i, fork=False)
         else:
-            self._nms(i, fork=True)   # (the letterbox enqueued BEFORE the sort pass, so that it starts ~5 us sooner: the sort
-            self.side.wait_event(self.decode_done)   # workgroups then queue behind its tiles -- seg640 1.206 -> 1.234, det640 0.124 -> 0.148 ms/step)
+            # The sort pass is enqueued BEFORE the letterbox on purpose.  Of the candidate filter's two successors in the
+            # graph the one enqueued first starts ~5 us sooner; with the letterbox first the sort workgroups queue behind
+            # its tiles: seg640 1.206 -> 1.234, det640 0.124 -> 0.148 ms per step (profiles/r03/fill_pacing.md).
+            self._nms(i, fork=True)
+            self.side.wait_event(self.decode_done)
             with torch.cuda.stream(self.side):
                 self._letterbox(i, time_letterbox)
         # join=False (detection workloads inside a block graph): the next step's candidate filter need not wait for this
