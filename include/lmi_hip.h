@@ -113,7 +113,8 @@ typedef struct lmi_frame {
  *   frames_dev  [device] the same array in device memory, read by the kernels
  *   swap_rb != 0 reverses the channel order (BGR<->RGB); pad_value in 0..255.
  *   workspace   [device] >= lmi_letterbox_workspace_bytes(batch, dst_h, dst_w) bytes, 256-byte
- *               aligned: the per-frame coefficient tables, rebuilt by every call
+ *               aligned: the per-frame coefficient tables, rebuilt by every call (unless mode carries
+ *               LMI_LB_TABLES_READY, above)
  * mode = LMI_RESIZE_TORCH_BILINEAR swaps the resampler for the reference's own helper flavour
  *   `resize_image` + `fit_im_to_size`   lmi_utils/gadget_utils/pipeline_utils.py:23-142, as chained by
  *                                        object_detectors/ultralytics_lmi/yolo/run_model.py:87-100

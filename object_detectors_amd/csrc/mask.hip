@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void mask_zero_fill_kernel(const int *__restri
   // r03: the workgroup's four waves are kept in step by one bare s_barrier per trip (the instruction alone: no wait for
   // the stores, which a __syncthreads() would add).  Left to themselves the waves drift apart and the window frays:
   // 6.28-6.37 TB/s without, 6.46-6.54 with the barrier on the same 6.18 GB (scratch/fill_skip.hip,
-  // profiles/r03/fill_skip.md; hipMemset: 6.25-6.40).  The trip count is the same for every lane of the workgroup.
+  // profiles/r03/fill_pacing.md; hipMemset: 6.25-6.40).  The trip count is the same for every lane of the workgroup.
   for (long long base = (long long)blockIdx.x * 256; base < n; base += stride) {
     const long long g = base + threadIdx.x;
     if (g < n) __builtin_nontemporal_store(zero, o + g);   // plain stores run as fast here but leave write-backs that slow the next kernels

@@ -167,6 +167,10 @@ def letterbox_tables(frame_hw: Tuple[int, int], dst_hw: Tuple[int, int], device,
     h, w = int(frame_hw[0]), int(frame_hw[1])
     dst_h, dst_w = int(dst_hw[0]), int(dst_hw[1])
     device = torch.device(device)
+    if device.type != "cuda":
+        raise TypeError("letterbox_tables: the tables live on the GPU (there is no CPU fallback for this path)")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     t = torch.empty((int(_L.lmi_letterbox_workspace_bytes(1, dst_h, dst_w)),), dtype=torch.uint8, device=device)
     check(_L.lmi_letterbox_u8_uniform(None, 1, h, w, 3 * w, 3 * w * h, None, dst_h, dst_w, LMI_F32, 0, 0, int(stretch),
                                       _lib.LMI_LB_TABLES_ONLY, t.data_ptr(), t.numel(), _stream(device)))

@@ -80,7 +80,7 @@ def test_letterbox_plan_execute_tables_built_once(ops):
     dtype or grey / colour -- and a buffer built for another geometry is refused."""
     rng = np.random.default_rng(77)
     for h, w, sh, sw, stretch in [(375, 500, 640, 640, False), (1080, 1920, 640, 640, False), (33, 77, 96, 128, True)]:
-        tabs = ops.letterbox_tables((h, w), (sh, sw), "cuda:0", stretch=stretch)
+        tabs = ops.letterbox_tables((h, w), (sh, sw), "cuda" if stretch else "cuda:0", stretch=stretch)   # "cuda": the current device
         for swap, pad, fp16, grey in [(True, 114, False, False), (False, 0, True, False), (True, 7, False, True)]:
             frames = synth.frames_u8(rng, 3, h, w)
             f = frames[..., :1] if grey else frames
