@@ -366,6 +366,13 @@ def main():
         # process has touched the GPU (it never does), pass the child's output through and leave with its status
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    # stdout carries ONE line, the JSON: RCCL and gloo print banners on the C-level stdout when a process group comes up
+    # ("RCCL version : ...", "[Gloo] Rank 0 is connected to ..."), so file descriptor 1 is pointed at stderr for the whole
+    # run and the line goes out through a duplicate of the original descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -611,7 +618,8 @@ def main():
                                    + (" -- REHEARSAL: all ranks share cuda:0 (LMI_BENCH_SHARE_DEVICE), the value is not a multi-GPU number" if share else "")},
             "roofline": roof, "cpu_baseline": cpu, "nms": nms_t, "letterbox": lb_t,
         }
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
